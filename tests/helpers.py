@@ -1,0 +1,97 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import json
+import os
+
+import numpy as np
+
+from oracle.pyoracle import CRS
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_MATS = ["FDM-2d-16", "matrix_band_klein", "hpcg8", "hpcg_4x6x5",
+               "anderson8_shift9", "anderson6_raw"]
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, f"golden_{name}.npz")))
+
+
+def crs_of(g, prefix):
+    rp = g[prefix + "_rp"]
+    return CRS(len(rp) - 1, rp, g[prefix + "_col"], g[prefix + "_val"])
+
+
+def load_histories():
+    with open(os.path.join(GOLDEN, "histories.json")) as f:
+        return json.load(f)
+
+
+def parse_hist_key(key):
+    name, solver, pc, kws = key.split("|")
+    kw = {}
+    for item in filter(None, kws.split(",")):
+        k, v = item.split("=")
+        kw[k] = (v == "True") if v in ("True", "False") else int(v)
+    return name, solver, pc, kw
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    denom = np.max(np.abs(b)) if b.size else 1.0
+    if denom == 0.0:
+        denom = 1.0
+    return float(np.max(np.abs(a - b)) / denom) if a.size else 0.0
+
+
+def hist_dev(h, g):
+    """max_k |h_k - g_k| / g_0 over the common window."""
+    n = min(len(h), len(g))
+    h = np.asarray(h[:n])
+    g = np.asarray(g[:n])
+    return float(np.max(np.abs(h - g)) / g[0])
+
+
+# Residual-history parity gate (SURVEY.md section 8d / section 7 "parity
+# tolerance").  All deviations are max_k |r_k - r_k^ref| / r_0.
+#   CG / Jacobi / GS / SGS      : 1e-10 over the whole history
+#   BiCGSTAB                    : 1e-10 over the first 2 iterations, 1e-4 over
+#       the whole history -- BiCGSTAB amplifies rounding differences (1e-16
+#       -> 6e-7 at iteration 3 on matrix_band_klein -bi -p sgs): the
+#       reference itself moves by 9.3e-6 between 1 and 8 threads (HPCG-64,
+#       SURVEY.md section 7) and by 6.3e-5 against a differently-rounded
+#       restatement on matrix_band_klein (-bi -p gs)
+#   GMRES                       : 1e-10 over the whole history (preconditioned
+#       residual estimate |g_{j+1}|)
+# Iteration counts are compared exactly only where the stopping decision is
+# not a rounding tie: TOL = 1e-14 puts the threshold at the rounding floor, so
+# two correct implementations may stop one rounding-level iteration apart
+# (seen for GMRES on FDM-2d-16: 34 vs 51 iterations with |dr| = 4e-14 r0).
+HIST_TOL = {"cg": 1e-10, "j": 1e-10, "gs": 1e-10, "sgs": 1e-10, "gm": 1e-10,
+            "bi": 1e-4}
+
+
+def check_history(r, e, solver, scale=1.0):
+    g = np.array(e["hist"])
+    h = np.asarray(r["hist"])
+    tol = HIST_TOL[solver] * scale
+    unstable = bool(np.any(g > 1e3 * g[0])) or not np.all(np.isfinite(g))
+    if unstable:
+        # divergent / chaotic in the reference itself: compare until the
+        # history leaves 1e3 * r0 (at most 50 iterations), loosely
+        bad = ~(g <= 1e3 * g[0])
+        n = int(np.argmax(bad)) if np.any(bad) else len(g)
+        n = max(1, min(n, 50, len(h)))
+        assert hist_dev(h[:n], g[:n]) <= 1e-8
+        return
+    if solver == "bi":
+        k = min(3, len(g), len(h))
+        assert hist_dev(h[:k], g[:k]) <= 1e-10 * scale
+    assert hist_dev(h, g) <= tol
+    if e["iters"] is not None and solver in ("cg", "j", "gs", "sgs"):
+        n = min(len(h), len(g))
+        if len(h) != len(g):
+            # allowed only as a rounding tie at the stopping threshold
+            assert abs(len(h) - len(g)) <= 2
+            assert abs(h[n - 1] - g[n - 1]) <= tol * g[0]
+        else:
+            assert r["converged"] == e["converged"]
