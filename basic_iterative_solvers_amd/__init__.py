@@ -1,0 +1,298 @@
+"""basic_iterative_solvers_amd -- MI355X (gfx950) implementation of the SpMV +
+preconditioner-apply + BLAS-1 hot path of DanecLacey/basic_iterative_solvers.
+
+The product is the C-ABI library `lib/libbis_hip.so` (include/bis_hip.h),
+hand-written HIP for gfx950, plus the C++ host layer under `host/` that mirrors
+the reference's operator surface.  This Python module is only a thin ctypes
+binding used by the tests, `bench.py` and `__graft_entry__.py`; it adds no
+compute path of its own and there is no CPU fallback: without a usable gfx950
+device `Context()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libbis_hip.so")
+
+PC = dict(none=0, j=1, gs=2, bgs=3, sgs=4, **{"2st": 5, "s2st": 6, "ilu0": 7})
+
+_lib = None
+
+
+class BisError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the in-tree C-ABI library (never builds, never falls back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BisError(
+                f"{LIB_PATH} is missing: build it with "
+                "`python -m basic_iterative_solvers_amd.build` (hipcc, gfx950)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.bis_last_error.restype = C.c_char_p
+        _lib.bis_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def _i64(v):
+    return C.c_int64(int(v))
+
+
+class Context:
+    """bis_ctx: one device + stream.  Raises if no gfx950 device is usable."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        st = self.lib.bis_ctx_create(C.c_int(device), C.c_void_p(stream), C.byref(self.h))
+        if st != 0:
+            raise BisError(f"bis_ctx_create failed (status {st}): no usable gfx950 device; "
+                           "this package has no CPU fallback")
+
+    def check(self, st):
+        if st != 0:
+            raise BisError(f"status {st}: {self.lib.bis_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.bis_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def sync(self):
+        self.check(self.lib.bis_sync(self.h))
+
+    def device_info(self):
+        arch = C.create_string_buffer(64)
+        n_cus = C.c_int()
+        hbm = C.c_int64()
+        self.check(self.lib.bis_device_info(self.h, arch, C.c_size_t(64), C.byref(n_cus),
+                                            C.byref(hbm)))
+        return dict(arch=arch.value.decode(), n_cus=n_cus.value, hbm_bytes=hbm.value)
+
+    # ---- vectors -----------------------------------------------------------
+    def alloc(self, n):
+        p = C.c_void_p()
+        self.check(self.lib.bis_vec_alloc(self.h, _i64(n), C.byref(p)))
+        return Vec(self, p.value, int(n), True)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        v = self.alloc(arr.size)
+        self.check(self.lib.bis_vec_upload(self.h, C.c_void_p(v.ptr), arr.ctypes, _i64(arr.size)))
+        return v
+
+    # ---- matrices ----------------------------------------------------------
+    def matrix(self, crs):
+        """Upload a host CRS (object with n_rows, n_cols, row_ptr(int64), col, val)."""
+        h = C.c_void_p()
+        rp = np.ascontiguousarray(crs.row_ptr, dtype=np.int64)
+        col = np.ascontiguousarray(crs.col, dtype=np.int32)
+        val = np.ascontiguousarray(crs.val, dtype=np.float64)
+        nnz = int(rp[-1]) if len(rp) else 0
+        if nnz < 2 ** 31 - 16:
+            rp32 = rp.astype(np.int32)
+            st = self.lib.bis_mat_create(self.h, _i64(crs.n_rows), _i64(crs.n_cols), _i64(nnz),
+                                         rp32.ctypes, col.ctypes, val.ctypes, C.byref(h))
+        else:
+            st = self.lib.bis_mat_create64(self.h, _i64(crs.n_rows), _i64(crs.n_cols), _i64(nnz),
+                                           rp.ctypes, col.ctypes, val.ctypes, C.byref(h))
+        self.check(st)
+        return Mat(self, h)
+
+    def gen_hpcg(self, nx, ny=None, nz=None, row0=0, row1=None):
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        row1 = nx * ny * nz if row1 is None else row1
+        h = C.c_void_p()
+        self.check(self.lib.bis_mat_gen_hpcg(self.h, _i64(nx), _i64(ny), _i64(nz), _i64(row0),
+                                             _i64(row1), C.byref(h)))
+        return Mat(self, h)
+
+    def gen_anderson(self, L, t=1.0, W=5.0, shift=0.0, seed=1, row0=0, row1=None):
+        row1 = L ** 3 if row1 is None else row1
+        h = C.c_void_p()
+        self.check(self.lib.bis_mat_gen_anderson(self.h, _i64(L), C.c_double(t), C.c_double(W),
+                                                 C.c_double(shift), C.c_uint64(seed),
+                                                 _i64(row0), _i64(row1), C.byref(h)))
+        return Mat(self, h)
+
+    def split_strict(self, A):
+        n = A.n_rows
+        D, Dinv = self.alloc(n), self.alloc(n)
+        hl, hu = C.c_void_p(), C.c_void_p()
+        self.check(self.lib.bis_mat_split_strict(self.h, A.h, C.byref(hl), C.byref(hu),
+                                                 C.c_void_p(D.ptr), C.c_void_p(Dinv.ptr)))
+        return Mat(self, hl), Mat(self, hu), D, Dinv
+
+    # ---- kernels (kernels.hpp names) ---------------------------------------
+    def spmv(self, A, x, y):
+        self.check(self.lib.bis_spmv(self.h, A.h, C.c_void_p(x.ptr), C.c_void_p(y.ptr)))
+
+    def sptrsv(self, Ls, x, D, b):
+        self.check(self.lib.bis_sptrsv(self.h, Ls.h, C.c_void_p(x.ptr), C.c_void_p(D.ptr),
+                                       C.c_void_p(b.ptr)))
+
+    def bsptrsv(self, Us, x, D, b):
+        self.check(self.lib.bis_bsptrsv(self.h, Us.h, C.c_void_p(x.ptr), C.c_void_p(D.ptr),
+                                        C.c_void_p(b.ptr)))
+
+    def _ew3(self, fn, r, a, b, scale, n=None):
+        n = r.n if n is None else n
+        self.check(fn(self.h, C.c_void_p(r.ptr), C.c_void_p(a.ptr), C.c_void_p(b.ptr), _i64(n),
+                      C.c_double(scale)))
+
+    def subtract_vectors(self, r, a, b, scale=1.0, n=None):
+        self._ew3(self.lib.bis_subtract_vectors, r, a, b, scale, n)
+
+    def sum_vectors(self, r, a, b, scale=1.0, n=None):
+        self._ew3(self.lib.bis_sum_vectors, r, a, b, scale, n)
+
+    def elemwise_mult_vectors(self, r, a, b, scale=1.0, n=None):
+        self._ew3(self.lib.bis_elemwise_mult_vectors, r, a, b, scale, n)
+
+    def elemwise_div_vectors(self, r, a, b, scale=1.0, n=None):
+        self._ew3(self.lib.bis_elemwise_div_vectors, r, a, b, scale, n)
+
+    def compute_residual(self, A, x, b, res, tmp):
+        self.check(self.lib.bis_compute_residual(self.h, A.h, C.c_void_p(x.ptr), C.c_void_p(b.ptr),
+                                                 C.c_void_p(res.ptr), C.c_void_p(tmp.ptr)))
+
+    def dot(self, a, b, n=None):
+        out = C.c_double()
+        self.check(self.lib.bis_dot(self.h, C.c_void_p(a.ptr), C.c_void_p(b.ptr),
+                                    _i64(a.n if n is None else n), C.byref(out)))
+        return out.value
+
+    def euclidean_vec_norm(self, v, n=None):
+        out = C.c_double()
+        self.check(self.lib.bis_euclidean_vec_norm(self.h, C.c_void_p(v.ptr),
+                                                   _i64(v.n if n is None else n), C.byref(out)))
+        return out.value
+
+    def scale(self, r, v, scalar, n=None):
+        self.check(self.lib.bis_scale(self.h, C.c_void_p(r.ptr), C.c_void_p(v.ptr),
+                                      C.c_double(scalar), _i64(r.n if n is None else n)))
+
+    def init_vector(self, v, val, n=None):
+        self.check(self.lib.bis_init_vector(self.h, C.c_void_p(v.ptr), C.c_double(val),
+                                            _i64(v.n if n is None else n)))
+
+    def copy_vector(self, out, inp, n=None):
+        self.check(self.lib.bis_copy_vector(self.h, C.c_void_p(out.ptr), C.c_void_p(inp.ptr),
+                                            _i64(out.n if n is None else n)))
+
+    def normalize_x(self, x_new, x_old, D, b):
+        self.check(self.lib.bis_normalize_x(self.h, C.c_void_p(x_new.ptr), C.c_void_p(x_old.ptr),
+                                            C.c_void_p(D.ptr), C.c_void_p(b.ptr), _i64(x_new.n)))
+
+    def multi_axpy(self, V, ldv, y_host, n_vec, out, n):
+        y = np.ascontiguousarray(y_host, dtype=np.float64)
+        self.check(self.lib.bis_multi_axpy(self.h, C.c_void_p(V.ptr), _i64(ldv), y.ctypes,
+                                           C.c_int(n_vec), C.c_void_p(out.ptr), _i64(n)))
+
+    def apply_preconditioner(self, pc, n, Ls, Us, A_D, A_D_inv, L_D, U_D, out, inp, tmp, work,
+                             outer=1, inner=0):
+        def p(v):
+            return C.c_void_p(v.ptr) if v is not None else C.c_void_p()
+        self.check(self.lib.bis_apply_preconditioner(
+            self.h, C.c_int(PC[pc] if isinstance(pc, str) else pc), _i64(n),
+            Ls.h if Ls is not None else C.c_void_p(), Us.h if Us is not None else C.c_void_p(),
+            p(A_D), p(A_D_inv), p(L_D), p(U_D), p(out), p(inp), p(tmp), p(work),
+            C.c_int(outer), C.c_int(inner)))
+
+    # ---- fused CG ------------------------------------------------------------
+    def cg(self, A, b, x, A_D=None):
+        return CG(self, A, b, x, A_D)
+
+    # ---- measurement ---------------------------------------------------------
+    def profile(self, on):
+        self.check(self.lib.bis_profile_enable(self.h, C.c_int(int(on))))
+
+    def profile_read(self):
+        n = C.c_int64()
+        ms = C.c_double()
+        self.check(self.lib.bis_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+class Vec:
+    """A device vector: raw `double*` + length (what the reference passes as
+    `double *`).  `offset(k)` gives the pointer-arithmetic view `&v[k]`
+    (gmres.hpp:169)."""
+
+    def __init__(self, ctx, ptr, n, owner):
+        self.ctx, self.ptr, self.n, self.owner = ctx, ptr, n, owner
+
+    def offset(self, k, n=None):
+        return Vec(self.ctx, self.ptr + 8 * int(k), self.n - int(k) if n is None else n, False)
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.bis_vec_download(self.ctx.h, out.ctypes, C.c_void_p(self.ptr),
+                                                     _i64(self.n)))
+        return out
+
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        assert arr.size == self.n
+        self.ctx.check(self.ctx.lib.bis_vec_upload(self.ctx.h, C.c_void_p(self.ptr), arr.ctypes,
+                                                   _i64(self.n)))
+
+    def free(self):
+        if self.owner and self.ptr:
+            self.ctx.lib.bis_vec_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+class Mat:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+        n_rows, n_cols, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        ctx.lib.bis_mat_info(h, C.byref(n_rows), C.byref(n_cols), C.byref(nnz))
+        self.n_rows, self.n_cols, self.nnz = n_rows.value, n_cols.value, nnz.value
+
+    def download(self):
+        rp = np.zeros(self.n_rows + 1, dtype=np.int64)
+        col = np.zeros(self.nnz, dtype=np.int32)
+        val = np.zeros(self.nnz, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.bis_mat_download(self.ctx.h, self.h, rp.ctypes, col.ctypes,
+                                                     val.ctypes))
+        return rp, col, val
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.bis_mat_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+class CG:
+    def __init__(self, ctx, A, b, x, A_D=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.bis_cg_create(ctx.h, A.h, C.c_void_p(A_D.ptr) if A_D else C.c_void_p(),
+                                        C.c_void_p(b.ptr), C.c_void_p(x.ptr), C.byref(self.h)))
+
+    def init(self, tol):
+        r0 = C.c_double()
+        self.ctx.check(self.ctx.lib.bis_cg_init(self.ctx.h, self.h, C.c_double(tol), C.byref(r0)))
+        return r0.value
+
+    def iterate(self, n):
+        self.ctx.check(self.ctx.lib.bis_cg_iterate(self.ctx.h, self.h, C.c_int(n)))
+
+    def status(self, hist_cap=4096):
+        iters, conv = C.c_int(), C.c_int()
+        hist = np.zeros(hist_cap)
+        self.ctx.check(self.ctx.lib.bis_cg_status(self.ctx.h, self.h, C.byref(iters), C.byref(conv),
+                                                  hist.ctypes, C.c_int(hist_cap)))
+        return iters.value, bool(conv.value), hist[:min(iters.value + 1, hist_cap)].copy()
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.bis_cg_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()

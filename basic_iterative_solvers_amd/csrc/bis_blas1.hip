@@ -1,0 +1,463 @@
+// bis_blas1.hip -- context, vectors and the BLAS-1 class kernels of the hot
+// path (reference kernels.hpp:119-257, methods/jacobi.hpp:27-40) as
+// hand-written gfx950 HIP kernels.  All of them are HBM-bound streaming
+// kernels: 16 B per lane (double2) loads/stores, grid capped at 2048
+// workgroups with a grid-stride loop (cdna_hip_programming.md Guideline 11/13).
+#include "bis_internal.hpp"
+
+namespace {
+
+constexpr int kEwThreads = 256;
+
+inline int ew_grid(int64_t n_items) {
+    int64_t g = (n_items + kEwThreads - 1) / kEwThreads;
+    if (g < 1) g = 1;
+    if (g > kMaxReduceBlocks) g = kMaxReduceBlocks;
+    return (int)g;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+enum { OP_SUB, OP_SUM, OP_MUL, OP_DIV };
+
+template <int OP>
+__device__ __forceinline__ double ew_apply(double a, double b, double s) {
+    if (OP == OP_SUB) return fma(-s, b, a);      // a - s*b   kernels.hpp:124
+    if (OP == OP_SUM) return fma(s, b, a);       // a + s*b   kernels.hpp:133
+    if (OP == OP_MUL) return (a * s) * b;        // a*s*b     kernels.hpp:142
+    return a / (s * b);                          // a/(s*b)   kernels.hpp:151
+}
+
+// r = op(a, b, s).  r may alias a and/or b (same-index access only).
+template <int OP, bool VEC>
+__global__ __launch_bounds__(kEwThreads) void ew3_kernel(double *r, const double *a,
+                                                         const double *b, int64_t n,
+                                                         double s) {
+    const int64_t stride = (int64_t)gridDim.x * kEwThreads;
+    int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
+    if (VEC) {
+        const int64_t n2 = n >> 1;
+        const double2 *a2 = reinterpret_cast<const double2 *>(a);
+        const double2 *b2 = reinterpret_cast<const double2 *>(b);
+        double2 *r2 = reinterpret_cast<double2 *>(r);
+        for (; i < n2; i += stride) {
+            double2 av = a2[i], bv = b2[i], rv;
+            rv.x = ew_apply<OP>(av.x, bv.x, s);
+            rv.y = ew_apply<OP>(av.y, bv.y, s);
+            r2[i] = rv;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+            r[n - 1] = ew_apply<OP>(a[n - 1], b[n - 1], s);
+    } else {
+        for (; i < n; i += stride) r[i] = ew_apply<OP>(a[i], b[i], s);
+    }
+}
+
+enum { U_SCALE, U_COPY, U_FILL };
+
+template <int OP, bool VEC>
+__global__ __launch_bounds__(kEwThreads) void ew2_kernel(double *r, const double *a,
+                                                         int64_t n, double s) {
+    const int64_t stride = (int64_t)gridDim.x * kEwThreads;
+    int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
+    if (VEC) {
+        const int64_t n2 = n >> 1;
+        const double2 *a2 = reinterpret_cast<const double2 *>(a);
+        double2 *r2 = reinterpret_cast<double2 *>(r);
+        for (; i < n2; i += stride) {
+            double2 rv;
+            if (OP == U_FILL) {
+                rv.x = s; rv.y = s;
+            } else {
+                double2 av = a2[i];
+                rv.x = (OP == U_SCALE) ? av.x * s : av.x;
+                rv.y = (OP == U_SCALE) ? av.y * s : av.y;
+            }
+            r2[i] = rv;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+            r[n - 1] = (OP == U_FILL) ? s : ((OP == U_SCALE) ? a[n - 1] * s : a[n - 1]);
+    } else {
+        for (; i < n; i += stride)
+            r[i] = (OP == U_FILL) ? s : ((OP == U_SCALE) ? a[i] * s : a[i]);
+    }
+}
+
+// normalize_x, methods/jacobi.hpp:27-40.
+__global__ __launch_bounds__(kEwThreads) void normalize_x_kernel(double *x_new,
+                                                                 const double *x_old,
+                                                                 const double *D,
+                                                                 const double *b,
+                                                                 int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kEwThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += stride) {
+        const double d = D[i];
+        const double adjusted = fma(-d, x_old[i], x_new[i]);
+        x_new[i] = (b[i] - adjusted) / d;
+    }
+}
+
+// out[i] = sum_{k<n_vec} V[k*ldv+i]*y[k], accumulated in k order
+// (kernels.hpp:259-271 as called from gmres.hpp:358).
+struct MultiAxpyCoef { double y[64]; };
+__global__ __launch_bounds__(kEwThreads) void multi_axpy_kernel(const double *V, int64_t ldv,
+                                                                MultiAxpyCoef c, int n_vec,
+                                                                double *out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kEwThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += stride) {
+        double acc = 0.0;
+        for (int k = 0; k < n_vec; ++k) acc = fma(V[(int64_t)k * ldv + i], c.y[k], acc);
+        out[i] = acc;
+    }
+}
+
+// partials[blockIdx.x] = sum over this block's grid-stride share of a[i]*b[i].
+template <bool VEC>
+__global__ __launch_bounds__(kEwThreads) void dot_partial_kernel(const double *a,
+                                                                 const double *b, int64_t n,
+                                                                 double *partials) {
+    __shared__ double lds[kEwThreads / 64];
+    const int64_t stride = (int64_t)gridDim.x * kEwThreads;
+    int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (VEC) {
+        const int64_t n2 = n >> 1;
+        const double2 *a2 = reinterpret_cast<const double2 *>(a);
+        const double2 *b2 = reinterpret_cast<const double2 *>(b);
+        for (; i < n2; i += stride) {
+            double2 av = a2[i], bv = b2[i];
+            acc0 = fma(av.x, bv.x, acc0);
+            acc1 = fma(av.y, bv.y, acc1);
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+            acc0 = fma(a[n - 1], b[n - 1], acc0);
+    } else {
+        for (; i < n; i += stride) acc0 = fma(a[i], b[i], acc0);
+    }
+    const double s = block_sum<kEwThreads>(acc0 + acc1, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// result[v] = sum_i partials[v*stride + i], fixed order.
+__global__ __launch_bounds__(256) void reduce_finish_kernel(const double *partials,
+                                                            int n_partials, size_t stride,
+                                                            double *result) {
+    __shared__ double lds[4];
+    const double *p = partials + (size_t)blockIdx.x * stride;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_partials; i += 256) acc += p[i];
+    const double s = block_sum<256>(acc, lds);
+    if (threadIdx.x == 0) result[blockIdx.x] = s;
+}
+
+} // namespace
+
+bis_status bis_reduce_finish(bis_ctx *ctx, int n_partials, int n_values, size_t stride,
+                             double *result_dev) {
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(n_values), dim3(256), 0, ctx->stream,
+                       ctx->partials, n_partials, stride, result_dev);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+
+bis_status bis_ensure_partials(bis_ctx *ctx, size_t n) {
+    if (n <= ctx->partials_cap) return BIS_OK;
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->partials) BIS_HIP_CHECK(ctx, hipFree(ctx->partials));
+    ctx->partials = nullptr;
+    ctx->partials_cap = 0;
+    BIS_HIP_CHECK(ctx, hipMalloc(&ctx->partials, sizeof(double) * n));
+    ctx->partials_cap = n;
+    return BIS_OK;
+}
+
+// ---- context ------------------------------------------------------------------
+extern "C" {
+
+int bis_abi_version(void) { return 1; }
+
+bis_status bis_ctx_create(int device, void *stream, bis_ctx **out) {
+    if (!out) return BIS_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return BIS_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return BIS_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return BIS_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BIS_ERR_NO_DEVICE;
+    bis_ctx *ctx = new bis_ctx;
+    ctx->device = device;
+    ctx->n_cus = prop.multiProcessorCount;
+    ctx->arch = prop.gcnArchName;
+    ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (ctx->arch.rfind("gfx950", 0) != 0) {
+        // the code object in this library is gfx950-only; refuse loudly
+        fprintf(stderr, "bis_hip: device %d is %s, this library is built for gfx950 only\n",
+                device, ctx->arch.c_str());
+        delete ctx;
+        return BIS_ERR_NO_DEVICE;
+    }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return BIS_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    ctx->partials_cap = (size_t)kMaxReduceBlocks * 4;
+    bool ok = hipMalloc(&ctx->partials, sizeof(double) * ctx->partials_cap) == hipSuccess &&
+              hipMalloc(&ctx->scalars_dev, sizeof(double) * 64) == hipSuccess &&
+              hipHostMalloc(&ctx->scalars_host, sizeof(double) * 64) == hipSuccess &&
+              hipMalloc(&ctx->counters, sizeof(unsigned) * 64) == hipSuccess &&
+              hipMemset(ctx->counters, 0, sizeof(unsigned) * 64) == hipSuccess &&
+              hipMemset(ctx->scalars_dev, 0, sizeof(double) * 64) == hipSuccess;
+    if (!ok) {
+        delete ctx;
+        return BIS_ERR_HIP;
+    }
+    *out = ctx;
+    return BIS_OK;
+}
+
+bis_status bis_ctx_destroy(bis_ctx *ctx) {
+    BIS_CTX_OK(ctx);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->prof_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    hipFree(ctx->partials);
+    hipFree(ctx->scalars_dev);
+    hipHostFree(ctx->scalars_host);
+    hipFree(ctx->counters);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return BIS_OK;
+}
+
+const char *bis_last_error(const bis_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context (no usable gfx950 device)"; }
+
+bis_status bis_sync(bis_ctx *ctx) {
+    BIS_CTX_OK(ctx);
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return BIS_OK;
+}
+
+void *bis_ctx_stream(bis_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+bis_status bis_device_info(bis_ctx *ctx, char *arch, size_t arch_len, int *n_cus,
+                           int64_t *hbm_bytes) {
+    BIS_CTX_OK(ctx);
+    if (arch && arch_len) {
+        strncpy(arch, ctx->arch.c_str(), arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    if (n_cus) *n_cus = ctx->n_cus;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return BIS_OK;
+}
+
+// ---- vectors ------------------------------------------------------------------
+bis_status bis_vec_alloc(bis_ctx *ctx, int64_t n, double **out) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, out && n >= 0, "bis_vec_alloc: bad arguments");
+    void *p = nullptr;
+    BIS_HIP_CHECK(ctx, hipMalloc(&p, sizeof(double) * (size_t)(n > 0 ? n : 1)));
+    *out = (double *)p;
+    return BIS_OK;
+}
+
+bis_status bis_vec_free(bis_ctx *ctx, double *v) {
+    BIS_CTX_OK(ctx);
+    if (!v) return BIS_OK;
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    BIS_HIP_CHECK(ctx, hipFree(v));
+    return BIS_OK;
+}
+
+bis_status bis_vec_upload(bis_ctx *ctx, double *dst, const double *src, int64_t n) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (dst && src)), "bis_vec_upload: bad arguments");
+    if (n == 0) return BIS_OK;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
+                                      ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return BIS_OK;
+}
+
+bis_status bis_vec_download(bis_ctx *ctx, double *dst, const double *src, int64_t n) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (dst && src)), "bis_vec_download: bad arguments");
+    if (n == 0) return BIS_OK;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
+                                      ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return BIS_OK;
+}
+
+} // extern "C"
+
+// ---- elementwise ----------------------------------------------------------------
+template <int OP>
+static bis_status launch_ew3(bis_ctx *ctx, double *r, const double *a, const double *b,
+                             int64_t n, double s) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (r && a && b)), "elementwise kernel: bad arguments");
+    if (n == 0) return BIS_OK;
+    const bool vec = aligned16(r) && aligned16(a) && aligned16(b) && n >= 2;
+    if (vec)
+        hipLaunchKernelGGL((ew3_kernel<OP, true>), dim3(ew_grid(n >> 1)), dim3(kEwThreads), 0,
+                           ctx->stream, r, a, b, n, s);
+    else
+        hipLaunchKernelGGL((ew3_kernel<OP, false>), dim3(ew_grid(n)), dim3(kEwThreads), 0,
+                           ctx->stream, r, a, b, n, s);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+
+template <int OP>
+static bis_status launch_ew2(bis_ctx *ctx, double *r, const double *a, int64_t n, double s);
+
+extern "C" {
+
+bis_status bis_subtract_vectors(bis_ctx *ctx, double *r, const double *a, const double *b,
+                                int64_t n, double scale) {
+    return launch_ew3<OP_SUB>(ctx, r, a, b, n, scale);
+}
+bis_status bis_sum_vectors(bis_ctx *ctx, double *r, const double *a, const double *b, int64_t n,
+                           double scale) {
+    return launch_ew3<OP_SUM>(ctx, r, a, b, n, scale);
+}
+bis_status bis_elemwise_mult_vectors(bis_ctx *ctx, double *r, const double *a, const double *b,
+                                     int64_t n, double scale) {
+    return launch_ew3<OP_MUL>(ctx, r, a, b, n, scale);
+}
+bis_status bis_elemwise_div_vectors(bis_ctx *ctx, double *r, const double *a, const double *b,
+                                    int64_t n, double scale) {
+    return launch_ew3<OP_DIV>(ctx, r, a, b, n, scale);
+}
+
+} // extern "C"
+
+template <int OP>
+static bis_status launch_ew2(bis_ctx *ctx, double *r, const double *a, int64_t n, double s) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (r && (a || OP == U_FILL))),
+                "elementwise kernel: bad arguments");
+    if (n == 0) return BIS_OK;
+    const bool vec = aligned16(r) && (OP == U_FILL || aligned16(a)) && n >= 2;
+    if (vec)
+        hipLaunchKernelGGL((ew2_kernel<OP, true>), dim3(ew_grid(n >> 1)), dim3(kEwThreads), 0,
+                           ctx->stream, r, a, n, s);
+    else
+        hipLaunchKernelGGL((ew2_kernel<OP, false>), dim3(ew_grid(n)), dim3(kEwThreads), 0,
+                           ctx->stream, r, a, n, s);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+
+extern "C" {
+
+bis_status bis_scale(bis_ctx *ctx, double *r, const double *v, double scalar, int64_t n) {
+    return launch_ew2<U_SCALE>(ctx, r, v, n, scalar);
+}
+bis_status bis_init_vector(bis_ctx *ctx, double *v, double val, int64_t n) {
+    return launch_ew2<U_FILL>(ctx, v, nullptr, n, val);
+}
+bis_status bis_copy_vector(bis_ctx *ctx, double *out, const double *in, int64_t n) {
+    if (out == in) return ctx ? BIS_OK : BIS_ERR_NO_DEVICE;
+    return launch_ew2<U_COPY>(ctx, out, in, n, 0.0);
+}
+
+bis_status bis_normalize_x(bis_ctx *ctx, double *x_new, const double *x_old, const double *D,
+                           const double *b, int64_t n) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (x_new && x_old && D && b)), "bis_normalize_x: bad arguments");
+    if (n == 0) return BIS_OK;
+    hipLaunchKernelGGL(normalize_x_kernel, dim3(ew_grid(n)), dim3(kEwThreads), 0, ctx->stream,
+                       x_new, x_old, D, b, n);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+
+bis_status bis_multi_axpy(bis_ctx *ctx, const double *V, int64_t ldv, const double *y_host,
+                          int n_vec, double *out, int64_t n) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && n_vec >= 0 && n_vec <= 64 && (n == 0 || (V && out)) &&
+                         (n_vec == 0 || y_host),
+                "bis_multi_axpy: bad arguments (n_vec must be <= 64)");
+    if (n == 0) return BIS_OK;
+    MultiAxpyCoef c;
+    for (int k = 0; k < 64; ++k) c.y[k] = k < n_vec ? y_host[k] : 0.0;
+    hipLaunchKernelGGL(multi_axpy_kernel, dim3(ew_grid(n)), dim3(kEwThreads), 0, ctx->stream, V,
+                       ldv, c, n_vec, out, n);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+
+// ---- reductions -------------------------------------------------------------------
+bis_status bis_dot_dev(bis_ctx *ctx, const double *a, const double *b, int64_t n,
+                       double *result_dev) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && result_dev && (n == 0 || (a && b)), "bis_dot: bad arguments");
+    const bool vec = aligned16(a) && aligned16(b) && n >= 2;
+    const int grid = n == 0 ? 1 : (vec ? ew_grid(n >> 1) : ew_grid(n));
+    if (vec)
+        hipLaunchKernelGGL((dot_partial_kernel<true>), dim3(grid), dim3(kEwThreads), 0,
+                           ctx->stream, a, b, n, ctx->partials);
+    else
+        hipLaunchKernelGGL((dot_partial_kernel<false>), dim3(grid), dim3(kEwThreads), 0,
+                           ctx->stream, a, b, n, ctx->partials);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return bis_reduce_finish(ctx, grid, 1, 0, result_dev);
+}
+
+bis_status bis_sumsq_dev(bis_ctx *ctx, const double *v, int64_t n, double *result_dev) {
+    return bis_dot_dev(ctx, v, v, n, result_dev);
+}
+
+bis_status bis_dot(bis_ctx *ctx, const double *a, const double *b, int64_t n,
+                   double *result_host) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, result_host, "bis_dot: null result");
+    bis_status st = bis_dot_dev(ctx, a, b, n, ctx->scalars_dev);
+    if (st != BIS_OK) return st;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, ctx->scalars_dev, sizeof(double),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *result_host = ctx->scalars_host[0];
+    return BIS_OK;
+}
+
+bis_status bis_euclidean_vec_norm(bis_ctx *ctx, const double *v, int64_t n,
+                                  double *result_host) {
+    double ss = 0.0;
+    bis_status st = bis_dot(ctx, v, v, n, &ss);
+    if (st != BIS_OK) return st;
+    *result_host = sqrt(ss); // kernels.hpp:202
+    return BIS_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------
+bis_status bis_profile_enable(bis_ctx *ctx, int on) {
+    BIS_CTX_OK(ctx);
+    ctx->profile = on != 0;
+    return BIS_OK;
+}
+
+bis_status bis_profile_read(bis_ctx *ctx, int64_t *spmv_launches, double *spmv_ms) {
+    BIS_CTX_OK(ctx);
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        float t = 0.f;
+        BIS_HIP_CHECK(ctx, hipEventElapsedTime(&t, ctx->prof_events[i].first,
+                                               ctx->prof_events[i].second));
+        ms += t;
+    }
+    if (spmv_launches) *spmv_launches = (int64_t)ctx->prof_used;
+    if (spmv_ms) *spmv_ms = ms;
+    ctx->prof_used = 0;
+    return BIS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,301 @@
+// bis_cg.hip -- the CG iteration of the reference (methods/cg.hpp:6-54, the
+// residual sampling of :162-166 and the stopping test of solver.hpp:177-192)
+// as a fused, sync-free device schedule.
+//
+// Same arithmetic per element as the reference's separate passes:
+//   tmp   = A p                                   cg.hpp:16
+//   alpha = (r,z) / (tmp,p)                       cg.hpp:19-23
+//   x     = x + alpha p ;  r = r - alpha tmp      cg.hpp:28-31
+//   z     = M^-1 r  (None: copy, Jacobi: r/D)     cg.hpp:37-41, kernels.hpp:357,398
+//   beta  = (r_new,z_new) / (r,z)                 cg.hpp:47
+//   p     = z + beta p                            cg.hpp:52
+//   ||r_new||_2 recorded, stop test               cg.hpp:162-166, solver.hpp:177-192
+// but in three streaming passes separated by the two global reductions
+// (12*nnz + 92*N bytes per iteration, +16*N with Jacobi):
+//   pass A  SpMV with the (tmp,p) partial sums fused into its epilogue
+//   pass B  x/r/z update with the (r,z) and (r,r) partial sums fused
+//   pass C  p update
+// alpha, beta, the residual history and the stop flag live on the device; the
+// host only enqueues iterations and reads the status when it wants to.  Once
+// the stop test fires, the remaining enqueued passes are no-ops, so the result
+// is exactly the state at the reference's stopping iteration.
+#include "bis_internal.hpp"
+
+#include <cfloat>
+#include <cmath>
+
+struct bis_cg {
+    const bis_mat *A = nullptr;
+    const double *A_D = nullptr; // nullptr: no preconditioner
+    const double *b = nullptr;
+    double *x = nullptr;
+    int64_t n = 0;
+    double *p = nullptr, *r = nullptr, *z = nullptr, *tmp = nullptr;
+    double *sc = nullptr;   // device scalars, see enum below
+    int *flags = nullptr;   // device: [0] iters, [1] done, [2] converged
+    double *hist = nullptr; // device residual history
+    int hist_cap = 0;
+    int enqueued = 0;
+};
+
+namespace {
+
+enum { S_RZ = 0, S_PAP, S_RZ_NEW, S_RR, S_ALPHA, S_BETA, S_STOP, S_COUNT = 8 };
+constexpr int kT = 256;
+constexpr int kMaxIters = 1 << 20;
+
+// pass B: x += alpha p; r -= alpha tmp; z = r/D (or r); partial (r,z), (r,r)
+template <bool JACOBI>
+__global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, const double *__restrict__ sc,
+                                                       const int *__restrict__ flags,
+                                                       const double *__restrict__ p,
+                                                       const double *__restrict__ tmp,
+                                                       const double *__restrict__ D,
+                                                       double *__restrict__ x,
+                                                       double *__restrict__ r,
+                                                       double *__restrict__ z,
+                                                       double *__restrict__ partials,
+                                                       size_t stride) {
+    __shared__ double lds[kT / 64];
+    if (flags[1]) return;
+    const double alpha = sc[S_RZ] / sc[S_PAP];
+    const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kT;
+    double rz = 0.0, rr = 0.0;
+    const double2 *p2 = reinterpret_cast<const double2 *>(p);
+    const double2 *t2 = reinterpret_cast<const double2 *>(tmp);
+    const double2 *D2 = reinterpret_cast<const double2 *>(D);
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    double2 *z2 = reinterpret_cast<double2 *>(z);
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n2; i += gs) {
+        const double2 pv = p2[i], tv = t2[i];
+        double2 xv = x2[i], rv = r2[i], zv;
+        xv.x = fma(alpha, pv.x, xv.x);
+        xv.y = fma(alpha, pv.y, xv.y);
+        rv.x = fma(-alpha, tv.x, rv.x);
+        rv.y = fma(-alpha, tv.y, rv.y);
+        x2[i] = xv;
+        r2[i] = rv;
+        if (JACOBI) {
+            const double2 dv = D2[i];
+            zv.x = rv.x / (1.0 * dv.x);
+            zv.y = rv.y / (1.0 * dv.y);
+            z2[i] = zv;
+        } else {
+            zv = rv;
+        }
+        rz = fma(rv.x, zv.x, rz);
+        rz = fma(rv.y, zv.y, rz);
+        rr = fma(rv.x, rv.x, rr);
+        rr = fma(rv.y, rv.y, rr);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double xv = fma(alpha, p[i], x[i]);
+        const double rv = fma(-alpha, tmp[i], r[i]);
+        x[i] = xv;
+        r[i] = rv;
+        double zv = rv;
+        if (JACOBI) { zv = rv / (1.0 * D[i]); z[i] = zv; }
+        rz = fma(rv, zv, rz);
+        rr = fma(rv, rv, rr);
+    }
+    const double s0 = block_sum<kT>(rz, lds);
+    __syncthreads();
+    const double s1 = block_sum<kT>(rr, lds);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = s0; partials[stride + blockIdx.x] = s1; }
+}
+
+// sc[S_PAP] = sum of the SpMV's fused partials
+__global__ __launch_bounds__(1024) void cg_finish_pap_kernel(const double *partials, int n_partials,
+                                                             double *sc, const int *flags) {
+    __shared__ double lds[16];
+    if (flags[1]) return;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_partials; i += 1024) acc += partials[i];
+    const double s = block_sum<1024>(acc, lds);
+    if (threadIdx.x == 0) sc[S_PAP] = s;
+}
+
+// reduce (r,z), (r,r); record the residual norm; beta; stop test
+__global__ __launch_bounds__(256) void cg_scalars_kernel(const double *partials, int n_partials,
+                                                         size_t stride, double *sc, int *flags,
+                                                         double *hist, int hist_cap) {
+    __shared__ double lds[4];
+    if (flags[1]) return;
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = threadIdx.x; i < n_partials; i += 256) { a0 += partials[i]; a1 += partials[stride + i]; }
+    const double rz_new = block_sum<256>(a0, lds);
+    __syncthreads();
+    const double rr = block_sum<256>(a1, lds);
+    if (threadIdx.x == 0) {
+        const double rz_old = sc[S_RZ];
+        sc[S_BETA] = rz_new / rz_old;          // cg.hpp:47
+        sc[S_RZ] = rz_new;
+        sc[S_RR] = rr;
+        const double norm = sqrt(rr);          // cg.hpp:164
+        const int it = flags[0] + 1;           // solver_harness.hpp:21
+        flags[0] = it;
+        if (it < hist_cap) hist[it] = norm;    // solver.hpp:161-163
+        // check_stopping_criteria, solver.hpp:177-192 (max_iters is the host's)
+        const bool conv = fabs(norm) < sc[S_STOP];
+        const bool diverged = fabs(norm) > DBL_MAX || norm != norm;
+        if (conv || diverged) { flags[1] = 1; flags[2] = conv ? 1 : 0; }
+    }
+}
+
+// pass C: p = z + beta p   (None: z == r)
+__global__ __launch_bounds__(kT) void cg_p_update_kernel(int64_t n, const double *__restrict__ sc,
+                                                         const int *__restrict__ flags,
+                                                         const double *__restrict__ z,
+                                                         double *__restrict__ p) {
+    // NOTE: runs even when the stop test has just fired in this iteration --
+    // the reference also forms p_new before it checks (cg.hpp:52); p is not
+    // part of the result, so skipping it is equivalent and cheaper.
+    if (flags[1]) return;
+    const double beta = sc[S_BETA];
+    const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kT;
+    const double2 *z2 = reinterpret_cast<const double2 *>(z);
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n2; i += gs) {
+        const double2 zv = z2[i];
+        double2 pv = p2[i];
+        pv.x = fma(beta, pv.x, zv.x);
+        pv.y = fma(beta, pv.y, zv.y);
+        p2[i] = pv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = fma(beta, p[n - 1], z[n - 1]);
+}
+
+inline int grid_for(int64_t n) {
+    int64_t g = ((n >> 1) + kT - 1) / kT;
+    if (g < 1) g = 1;
+    if (g > kMaxReduceBlocks) g = kMaxReduceBlocks;
+    return (int)g;
+}
+
+} // namespace
+
+extern "C" {
+
+bis_status bis_cg_create(bis_ctx *ctx, const bis_mat *A, const double *A_D, const double *b,
+                         double *x, bis_cg **out) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A && b && x && out, "bis_cg_create: bad arguments");
+    BIS_REQUIRE(ctx, A->n_rows == A->n_cols, "bis_cg_create: square matrix required");
+    bis_cg *cg = new bis_cg;
+    cg->A = A;
+    cg->A_D = A_D;
+    cg->b = b;
+    cg->x = x;
+    cg->n = A->n_rows;
+    cg->hist_cap = 4096;
+    bis_status st = bis_vec_alloc(ctx, cg->n, &cg->p);
+    if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->n, &cg->r);
+    if (st == BIS_OK && A_D) st = bis_vec_alloc(ctx, cg->n, &cg->z);
+    if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->n, &cg->tmp);
+    if (st == BIS_OK) st = bis_vec_alloc(ctx, S_COUNT, &cg->sc);
+    if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->hist_cap, &cg->hist);
+    if (st == BIS_OK && hipMalloc(&cg->flags, sizeof(int) * 4) != hipSuccess) st = BIS_ERR_HIP;
+    if (st != BIS_OK) { bis_cg_destroy(ctx, cg); return st; }
+    if (!A_D) cg->z = cg->r; // z aliases r without a preconditioner
+    *out = cg;
+    return BIS_OK;
+}
+
+bis_status bis_cg_destroy(bis_ctx *ctx, bis_cg *cg) {
+    BIS_CTX_OK(ctx);
+    if (!cg) return BIS_OK;
+    hipStreamSynchronize(ctx->stream);
+    hipFree(cg->p);
+    hipFree(cg->r);
+    if (cg->z != cg->r) hipFree(cg->z);
+    hipFree(cg->tmp);
+    hipFree(cg->sc);
+    hipFree(cg->hist);
+    hipFree(cg->flags);
+    delete cg;
+    return BIS_OK;
+}
+
+bis_status bis_cg_init(bis_ctx *ctx, bis_cg *cg, double tol, double *r0_norm_host) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, cg, "bis_cg_init: null handle");
+    const int64_t n = cg->n;
+    // init_residual, cg.hpp:100-118
+    bis_status st = bis_compute_residual(ctx, cg->A, cg->x, cg->b, cg->r, cg->tmp);
+    if (st == BIS_OK && cg->A_D) st = bis_elemwise_div_vectors(ctx, cg->z, cg->r, cg->A_D, n, 1.0);
+    if (st == BIS_OK) st = bis_copy_vector(ctx, cg->p, cg->z, n);
+    double rz = 0.0, rr = 0.0;
+    if (st == BIS_OK) st = bis_dot(ctx, cg->r, cg->z, n, &rz);
+    if (st == BIS_OK) st = bis_dot(ctx, cg->r, cg->r, n, &rr);
+    if (st != BIS_OK) return st;
+    const double norm0 = sqrt(rr);
+    double sc[S_COUNT] = {0};
+    sc[S_RZ] = rz;
+    sc[S_RR] = rr;
+    sc[S_STOP] = tol * norm0; // init_stopping_criteria, solver.hpp:173-175
+    int flags[4] = {0, 0, 0, 0};
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(cg->sc, sc, sizeof sc, hipMemcpyHostToDevice, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(cg->flags, flags, sizeof flags, hipMemcpyHostToDevice, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(cg->hist, &norm0, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    cg->enqueued = 0;
+    if (r0_norm_host) *r0_norm_host = norm0;
+    return BIS_OK;
+}
+
+bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, cg && n_iters >= 0 && cg->enqueued + n_iters < kMaxIters,
+                "bis_cg_iterate: bad arguments");
+    const int64_t n = cg->n;
+    if (n == 0) return BIS_OK;
+    const int g = grid_for(n);
+    bis_status st = bis_ensure_partials(ctx, (size_t)2 * kMaxReduceBlocks);
+    if (st != BIS_OK) return st;
+    for (int it = 0; it < n_iters; ++it) {
+        int n_part = 0;
+        st = bis_spmv_launch(ctx, cg->A, cg->p, cg->tmp, cg->p, &n_part);
+        if (st != BIS_OK) return st;
+        hipLaunchKernelGGL(cg_finish_pap_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials,
+                           n_part, cg->sc, cg->flags);
+        if (cg->A_D)
+            hipLaunchKernelGGL(cg_update_kernel<true>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc,
+                               cg->flags, cg->p, cg->tmp, cg->A_D, cg->x, cg->r, cg->z, ctx->partials,
+                               (size_t)kMaxReduceBlocks);
+        else
+            hipLaunchKernelGGL(cg_update_kernel<false>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc,
+                               cg->flags, cg->p, cg->tmp, cg->A_D, cg->x, cg->r, cg->z, ctx->partials,
+                               (size_t)kMaxReduceBlocks);
+        hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, g,
+                           (size_t)kMaxReduceBlocks, cg->sc, cg->flags, cg->hist, cg->hist_cap);
+        hipLaunchKernelGGL(cg_p_update_kernel, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags,
+                           cg->z, cg->p);
+    }
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    cg->enqueued += n_iters;
+    return BIS_OK;
+}
+
+bis_status bis_cg_status(bis_ctx *ctx, bis_cg *cg, int *iters, int *converged, double *hist_host,
+                         int hist_cap) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, cg, "bis_cg_status: null handle");
+    int flags[4] = {0, 0, 0, 0};
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(flags, cg->flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (iters) *iters = flags[0];
+    if (converged) *converged = flags[2];
+    if (hist_host && hist_cap > 0) {
+        int cnt = flags[0] + 1;
+        if (cnt > hist_cap) cnt = hist_cap;
+        if (cnt > cg->hist_cap) cnt = cg->hist_cap;
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(hist_host, cg->hist, sizeof(double) * (size_t)cnt,
+                                          hipMemcpyDeviceToHost, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return BIS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,144 @@
+// bis_internal.hpp -- shared internals of libbis_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bis_hip.h"
+
+struct bis_trsv_plan;
+
+struct bis_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cus = 0;
+    std::string arch;
+    int64_t hbm_bytes = 0;
+    std::string err;
+
+    // reduction scratch: per-block partials + result slots (device), and a
+    // pinned host mirror for blocking scalar returns
+    double *partials = nullptr;   // [partials_cap], grown on demand
+    size_t partials_cap = 0;
+    double *scalars_dev = nullptr; // [64]
+    double *scalars_host = nullptr; // pinned [64]
+    unsigned *counters = nullptr; // [64] tickets / arrival counters (zeroed)
+
+    // profiling
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+};
+
+constexpr int kMaxReduceBlocks = 2048;
+
+struct bis_mat {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    bool rp64 = false;        // row_ptr width on the device
+    void *row_ptr = nullptr;  // int32_t[n_rows+1] or int64_t[n_rows+1]
+    int32_t *col = nullptr;   // [nnz + pad]
+    double *val = nullptr;    // [nnz + pad]
+    // SpMV row-block metadata: block k covers rows [blk_row[k], blk_row[k+1])
+    int32_t *blk_row = nullptr;
+    int n_blocks = 0;
+    int chunk_nnz = 0;        // nnz budget per block used to build blk_row
+    int max_row_nnz = 0;
+    int64_t max_block_nnz = 0;
+    // triangular-solve plans (built lazily)
+    bis_trsv_plan *plan_fwd = nullptr;
+    bis_trsv_plan *plan_bwd = nullptr;
+};
+
+#define BIS_HIP_CHECK(ctx, call)                                               \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) {                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);    \
+            return BIS_ERR_HIP;                                                \
+        }                                                                      \
+    } while (0)
+
+#define BIS_REQUIRE(ctx, cond, msg)                                            \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            if (ctx) (ctx)->err = (msg);                                       \
+            return BIS_ERR_INVALID;                                            \
+        }                                                                      \
+    } while (0)
+
+#define BIS_CTX_OK(ctx)                                                        \
+    do {                                                                       \
+        if (!(ctx)) return BIS_ERR_NO_DEVICE;                                  \
+    } while (0)
+
+// ---- device helpers ---------------------------------------------------------
+// wave64 sum via DPP-free shuffles (ds_bpermute under the hood for doubles).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Block sum for blockDim.x == T (multiple of 64). Result valid in thread 0.
+template <int T>
+__device__ __forceinline__ double block_sum(double v, double *lds /*[T/64]*/) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < T / 64; ++i) r += lds[i];
+    }
+    return r;
+}
+
+// XCD-aware remap (cdna_hip_programming.md T1 / MI355X_MICROARCH.md "Workgroup
+// dispatch"): hardware deals workgroups round-robin over the 8 XCDs, so
+// blockIdx b lands on XCD b%8.  Map it to a logical block id such that each
+// XCD sweeps one contiguous range of logical blocks (its private L2 then sees
+// neighbouring rows / x-planes).  Valid for any n; ids >= n are skipped by the
+// caller.  Placement is a speed matter only.
+__device__ __forceinline__ int xcd_remap(int b, int n_padded8) {
+    const int per = n_padded8 >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+// HIP-event bracket around one launch (bis_profile_enable)
+inline void bis_prof_begin(bis_ctx *ctx) {
+    if (!ctx->profile) return;
+    if (ctx->prof_used == ctx->prof_events.size()) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        ctx->prof_events.emplace_back(a, b);
+    }
+    hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream);
+}
+inline void bis_prof_end(bis_ctx *ctx) {
+    if (!ctx->profile) return;
+    hipEventRecord(ctx->prof_events[ctx->prof_used].second, ctx->stream);
+    ++ctx->prof_used;
+}
+
+// result_dev[v] = sum_i partials[v*stride + i], i < n_partials (fixed order)
+bis_status bis_reduce_finish(bis_ctx *ctx, int n_partials, int n_values,
+                             size_t stride, double *result_dev);
+// make sure ctx->partials holds at least n doubles (stream-synchronising
+// only when it has to grow)
+bis_status bis_ensure_partials(bis_ctx *ctx, size_t n);
+bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x,
+                           double *y, const double *w, int *n_partials);
+
+// internal launchers shared between translation units
+bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols,
+                         int64_t nnz, bool rp64, bis_mat **out);
+bis_status bis_mat_finalize(bis_ctx *ctx, bis_mat *A);
+void bis_trsv_plan_destroy(bis_trsv_plan *p);

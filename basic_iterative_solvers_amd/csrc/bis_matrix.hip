@@ -1,0 +1,532 @@
+// bis_matrix.hip -- device-resident MatrixCRS (reference sparse_matrix.hpp:
+// 59-179), synthetic-input generators that build the CRS directly in HBM
+// (SURVEY.md section 8d), SpMV row-block metadata, and the device version of
+// the strict-triangle split + diagonal extraction (utilities/LU_factors.hpp:
+// 122-309, :827-869).
+//
+// HBM layout: row_ptr int32 (int64 when nnz >= 2^31), col int32, val fp64 --
+// the reference's layout (sparse_matrix.hpp:60-66), column order within a row
+// exactly as given.  col/val carry 8 elements of zero padding so that the
+// SpMV kernel's 16-byte vector loads may start 4-aligned before a block's
+// first non-zero and run past its last one.
+#include "bis_internal.hpp"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr int kPad = 8;
+
+template <typename RP>
+__global__ void max_row_kernel(const RP *row_ptr, int64_t n_rows, int *out_max) {
+    int m = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows;
+         r += (int64_t)gridDim.x * blockDim.x)
+        m = max(m, (int)(row_ptr[r + 1] - row_ptr[r]));
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out_max, m);
+}
+
+// blk_row[k] = first row r with row_ptr[r] >= k*chunk  (k = 0..n_blocks-1);
+// blk_row[n_blocks] = n_rows.
+template <typename RP>
+__global__ void row_blocks_kernel(const RP *row_ptr, int64_t n_rows, int n_blocks,
+                                  int64_t chunk, int32_t *blk_row) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_blocks) return;
+    if (k == n_blocks) { blk_row[k] = (int32_t)n_rows; return; }
+    const int64_t target = (int64_t)k * chunk;
+    int64_t lo = 0, hi = n_rows; // answer in [0, n_rows]
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    blk_row[k] = (int32_t)lo;
+}
+
+// ---- generators ---------------------------------------------------------------
+__device__ __forceinline__ int64_t hpcg_c(int64_t j, int64_t n) { return 1 + (j > 0) + (j < n - 1); }
+__device__ __forceinline__ int64_t hpcg_f(int64_t k, int64_t n) {
+    const int64_t a = k - 1 > 0 ? k - 1 : 0;
+    const int64_t b = k < n - 1 ? k : n - 1;
+    return k + a + b;
+}
+__host__ __device__ inline int64_t hpcg_f_h(int64_t k, int64_t n) {
+    const int64_t a = k - 1 > 0 ? k - 1 : 0;
+    const int64_t b = k < n - 1 ? k : n - 1;
+    return k + a + b;
+}
+__device__ __forceinline__ int64_t hpcg_row_ptr(int64_t row, int64_t nx, int64_t ny, int64_t nz) {
+    const int64_t Sx = hpcg_f(nx, nx), Sy = hpcg_f(ny, ny);
+    if (row >= nx * ny * nz) return hpcg_f(nz, nz) * Sy * Sx;
+    const int64_t x = row % nx, y = (row / nx) % ny, z = row / (nx * ny);
+    return hpcg_f(z, nz) * Sy * Sx + hpcg_c(z, nz) * (hpcg_f(y, ny) * Sx + hpcg_c(y, ny) * hpcg_f(x, nx));
+}
+static int64_t hpcg_row_ptr_host(int64_t row, int64_t nx, int64_t ny, int64_t nz) {
+    auto c = [](int64_t j, int64_t n) { return (int64_t)(1 + (j > 0) + (j < n - 1)); };
+    const int64_t Sx = hpcg_f_h(nx, nx), Sy = hpcg_f_h(ny, ny);
+    if (row >= nx * ny * nz) return hpcg_f_h(nz, nz) * Sy * Sx;
+    const int64_t x = row % nx, y = (row / nx) % ny, z = row / (nx * ny);
+    return hpcg_f_h(z, nz) * Sy * Sx + c(z, nz) * (hpcg_f_h(y, ny) * Sx + c(y, ny) * hpcg_f_h(x, nx));
+}
+
+template <typename RP>
+__global__ void gen_hpcg_kernel(int64_t nx, int64_t ny, int64_t nz, int64_t row0, int64_t row1,
+                                int64_t base, RP *row_ptr, int32_t *col, double *val) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = row0 + i;
+    if (row > row1) return;
+    int64_t p = hpcg_row_ptr(row, nx, ny, nz) - base;
+    row_ptr[i] = (RP)p;
+    if (row == row1) return;
+    const int64_t x = row % nx, y = (row / nx) % ny, z = row / (nx * ny);
+    for (int dz = -1; dz <= 1; ++dz) {
+        if (z + dz < 0 || z + dz >= nz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            if (y + dy < 0 || y + dy >= ny) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (x + dx < 0 || x + dx >= nx) continue;
+                col[p] = (int32_t)(row + dx + nx * (dy + ny * (int64_t)dz));
+                val[p] = (dx == 0 && dy == 0 && dz == 0) ? 26.0 : -1.0;
+                ++p;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double anderson_u01(uint64_t seed, uint64_t i) {
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + (i + 1) * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <typename RP>
+__global__ void gen_anderson_kernel(int64_t L, double t, double W, double shift, uint64_t seed,
+                                    int64_t row0, int64_t row1, RP *row_ptr, int32_t *col,
+                                    double *val) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = row0 + i;
+    if (row > row1) return;
+    row_ptr[i] = (RP)(i * 7);
+    if (row == row1) return;
+    const int64_t x = row % L, y = (row / L) % L, z = row / (L * L);
+    const int64_t xm = (x + L - 1) % L, xp = (x + 1) % L;
+    const int64_t ym = (y + L - 1) % L, yp = (y + 1) % L;
+    const int64_t zm = (z + L - 1) % L, zp = (z + 1) % L;
+    int64_t c[7];
+    double v[7];
+    c[0] = x + L * (y + L * zm);
+    c[1] = x + L * (ym + L * z);
+    c[2] = xm + L * (y + L * z);
+    c[3] = row;
+    c[4] = xp + L * (y + L * z);
+    c[5] = x + L * (yp + L * z);
+    c[6] = x + L * (y + L * zp);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = -t;
+    v[3] = fma(W, anderson_u01(seed, (uint64_t)row) - 0.5, shift);
+#pragma unroll
+    for (int a = 1; a < 7; ++a) { // insertion sort by column
+        const int64_t ck = c[a];
+        const double vk = v[a];
+        int b = a - 1;
+        while (b >= 0 && c[b] > ck) { c[b + 1] = c[b]; v[b + 1] = v[b]; --b; }
+        c[b + 1] = ck;
+        v[b + 1] = vk;
+    }
+    const int64_t p = i * 7;
+    for (int k = 0; k < 7; ++k) { col[p + k] = (int32_t)c[k]; val[p + k] = v[k]; }
+}
+
+// ---- strict split ---------------------------------------------------------------
+constexpr int kSplitT = 256;
+
+// per-row counts of strict-lower / strict-upper entries; per-block sums.
+// row0 = global index of local row 0 (columns are global).
+template <typename RP>
+__global__ __launch_bounds__(kSplitT) void split_count_kernel(const RP *row_ptr,
+                                                              const int32_t *col, int64_t n_rows,
+                                                              int64_t row0, int64_t *blk_l,
+                                                              int64_t *blk_u) {
+    __shared__ double lds[kSplitT / 64];
+    const int64_t r = (int64_t)blockIdx.x * kSplitT + threadIdx.x;
+    int cl = 0, cu = 0;
+    if (r < n_rows) {
+        const int64_t g = row0 + r;
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+            const int64_t c = col[k];
+            cl += c < g;
+            cu += c > g;
+        }
+    }
+    // counts fit a double exactly (< 2^53)
+    const double sl = block_sum<kSplitT>((double)cl, lds);
+    __syncthreads();
+    const double su = block_sum<kSplitT>((double)cu, lds);
+    if (threadIdx.x == 0) { blk_l[blockIdx.x] = (int64_t)sl; blk_u[blockIdx.x] = (int64_t)su; }
+}
+
+// exclusive scan of the block sums, single workgroup; totals to out2.
+__global__ __launch_bounds__(256) void split_scan_kernel(int64_t *blk_l, int64_t *blk_u, int n_blk,
+                                                         int64_t *out2) {
+    __shared__ int64_t sl[256], su[256];
+    int64_t run_l = 0, run_u = 0;
+    for (int base = 0; base < n_blk; base += 256) {
+        const int i = base + threadIdx.x;
+        const int64_t vl = i < n_blk ? blk_l[i] : 0, vu = i < n_blk ? blk_u[i] : 0;
+        sl[threadIdx.x] = vl;
+        su[threadIdx.x] = vu;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int64_t al = 0, au = 0;
+            if ((int)threadIdx.x >= off) { al = sl[threadIdx.x - off]; au = su[threadIdx.x - off]; }
+            __syncthreads();
+            sl[threadIdx.x] += al;
+            su[threadIdx.x] += au;
+            __syncthreads();
+        }
+        if (i < n_blk) { blk_l[i] = run_l + sl[threadIdx.x] - vl; blk_u[i] = run_u + su[threadIdx.x] - vu; }
+        run_l += sl[255];
+        run_u += su[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = run_l; out2[1] = run_u; }
+}
+
+// status word: 0 ok, else (1+row)<<1 | kind  (kind 0 = zero diag, 1 = no diag)
+template <typename RP, typename RPO>
+__global__ __launch_bounds__(kSplitT) void split_fill_kernel(
+    const RP *row_ptr, const int32_t *col, const double *val, int64_t n_rows, int64_t row0,
+    const int64_t *blk_l, const int64_t *blk_u, RPO *rpL, int32_t *colL, double *valL, RPO *rpU,
+    int32_t *colU, double *valU, double *D, double *D_inv, unsigned long long *status) {
+    __shared__ int64_t sl[kSplitT], su[kSplitT];
+    const int64_t r = (int64_t)blockIdx.x * kSplitT + threadIdx.x;
+    const int64_t g = row0 + r;
+    int cl = 0, cu = 0;
+    if (r < n_rows)
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+            const int64_t c = col[k];
+            cl += c < g;
+            cu += c > g;
+        }
+    sl[threadIdx.x] = cl;
+    su[threadIdx.x] = cu;
+    __syncthreads();
+    for (int off = 1; off < kSplitT; off <<= 1) {
+        int64_t al = 0, au = 0;
+        if ((int)threadIdx.x >= off) { al = sl[threadIdx.x - off]; au = su[threadIdx.x - off]; }
+        __syncthreads();
+        sl[threadIdx.x] += al;
+        su[threadIdx.x] += au;
+        __syncthreads();
+    }
+    if (r >= n_rows) return;
+    int64_t pl = blk_l[blockIdx.x] + sl[threadIdx.x] - cl;
+    int64_t pu = blk_u[blockIdx.x] + su[threadIdx.x] - cu;
+    rpL[r] = (RPO)pl;
+    rpU[r] = (RPO)pu;
+    if (r == n_rows - 1) { rpL[n_rows] = (RPO)(pl + cl); rpU[n_rows] = (RPO)(pu + cu); }
+    bool have_diag = false;
+    for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+        const int64_t c = col[k];
+        const double v = val[k];
+        if (c < g) { colL[pl] = (int32_t)c; valL[pl++] = v; }
+        else if (c > g) { colU[pu] = (int32_t)c; valU[pu++] = v; }
+        else { // peel_diag_crs keeps the LAST diagonal entry it meets (:843-857)
+            have_diag = true;
+            if (D) D[r] = v;
+            if (D_inv) D_inv[r] = 1.0 / v;
+            if (fabs(v) < 1e-16) atomicMin(status, ((unsigned long long)(g + 1) << 1) | 0ull);
+        }
+    }
+    if (!have_diag) atomicMin(status, ((unsigned long long)(g + 1) << 1) | 1ull);
+}
+
+template <typename RP>
+bis_status finalize_t(bis_ctx *ctx, bis_mat *A) {
+    const RP *rp = (const RP *)A->row_ptr;
+    int *d_max = (int *)ctx->counters + 32;
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(d_max, 0, sizeof(int), ctx->stream));
+    if (A->n_rows > 0) {
+        int grid = (int)std::min<int64_t>((A->n_rows + 255) / 256, 4096);
+        hipLaunchKernelGGL(max_row_kernel<RP>, dim3(grid), dim3(256), 0, ctx->stream, rp,
+                           A->n_rows, d_max);
+    }
+    int h_max = 0;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    A->max_row_nnz = h_max;
+    int chunk = 4096;
+    if (const char *e = getenv("BIS_SPMV_CHUNK")) chunk = std::max(256, atoi(e));
+    A->chunk_nnz = chunk;
+    int64_t nb = (A->nnz + chunk - 1) / chunk;
+    if (nb < 1) nb = 1;
+    A->n_blocks = (int)nb;
+    if (A->blk_row) hipFree(A->blk_row);
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->blk_row, sizeof(int32_t) * (size_t)(nb + 1)));
+    hipLaunchKernelGGL(row_blocks_kernel<RP>, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0,
+                       ctx->stream, rp, A->n_rows, (int)nb, (int64_t)chunk, A->blk_row);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+
+} // namespace
+
+bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, bool rp64,
+                         bis_mat **out) {
+    bis_mat *A = new bis_mat;
+    A->n_rows = n_rows;
+    A->n_cols = n_cols;
+    A->nnz = nnz;
+    A->rp64 = rp64;
+    const size_t rpb = (rp64 ? sizeof(int64_t) : sizeof(int32_t)) * (size_t)(n_rows + 1);
+    hipError_t e = hipMalloc(&A->row_ptr, rpb);
+    if (e == hipSuccess) e = hipMalloc(&A->col, sizeof(int32_t) * (size_t)(nnz + kPad));
+    if (e == hipSuccess) e = hipMalloc(&A->val, sizeof(double) * (size_t)(nnz + kPad));
+    if (e == hipSuccess) e = hipMemsetAsync(A->col + nnz, 0, sizeof(int32_t) * kPad, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(A->val + nnz, 0, sizeof(double) * kPad, ctx->stream);
+    if (e != hipSuccess) {
+        ctx->err = std::string("bis_mat_alloc: ") + hipGetErrorString(e);
+        hipFree(A->row_ptr); hipFree(A->col); hipFree(A->val);
+        delete A;
+        return BIS_ERR_HIP;
+    }
+    *out = A;
+    return BIS_OK;
+}
+
+bis_status bis_mat_finalize(bis_ctx *ctx, bis_mat *A) {
+    return A->rp64 ? finalize_t<int64_t>(ctx, A) : finalize_t<int32_t>(ctx, A);
+}
+
+extern "C" {
+
+static bis_status mat_create_common(bis_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                                    const void *row_ptr, bool src64, const int32_t *col,
+                                    const double *val, bis_mat **out) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, out && n_rows >= 0 && n_cols >= 0 && nnz >= 0 && row_ptr &&
+                         (nnz == 0 || (col && val)),
+                "bis_mat_create: bad arguments");
+    BIS_REQUIRE(ctx, n_rows < INT32_MAX && n_cols < INT32_MAX,
+                "bis_mat_create: row/column count must fit int32 (col is int32)");
+    const bool rp64 = nnz >= (int64_t)INT32_MAX - kPad;
+    bis_mat *A = nullptr;
+    bis_status st = bis_mat_alloc(ctx, n_rows, n_cols, nnz, rp64, &A);
+    if (st != BIS_OK) return st;
+    // convert row_ptr width on the host if source and device widths differ
+    std::vector<int64_t> tmp64;
+    std::vector<int32_t> tmp32;
+    const void *src = row_ptr;
+    if (src64 && !rp64) {
+        tmp32.resize(n_rows + 1);
+        for (int64_t i = 0; i <= n_rows; ++i) tmp32[i] = (int32_t)((const int64_t *)row_ptr)[i];
+        src = tmp32.data();
+    } else if (!src64 && rp64) {
+        tmp64.resize(n_rows + 1);
+        for (int64_t i = 0; i <= n_rows; ++i) tmp64[i] = ((const int32_t *)row_ptr)[i];
+        src = tmp64.data();
+    }
+    hipError_t e = hipMemcpyAsync(A->row_ptr, src, (rp64 ? 8 : 4) * (size_t)(n_rows + 1),
+                                  hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nnz)
+        e = hipMemcpyAsync(A->col, col, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nnz)
+        e = hipMemcpyAsync(A->val, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->err = std::string("bis_mat_create: ") + hipGetErrorString(e);
+        bis_mat_destroy(ctx, A);
+        return BIS_ERR_HIP;
+    }
+    st = bis_mat_finalize(ctx, A);
+    if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
+    *out = A;
+    return BIS_OK;
+}
+
+bis_status bis_mat_create(bis_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                          const int32_t *row_ptr, const int32_t *col, const double *val,
+                          bis_mat **out) {
+    return mat_create_common(ctx, n_rows, n_cols, nnz, row_ptr, false, col, val, out);
+}
+
+bis_status bis_mat_create64(bis_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                            const int64_t *row_ptr, const int32_t *col, const double *val,
+                            bis_mat **out) {
+    return mat_create_common(ctx, n_rows, n_cols, nnz, row_ptr, true, col, val, out);
+}
+
+bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A) {
+    BIS_CTX_OK(ctx);
+    if (!A) return BIS_OK;
+    hipStreamSynchronize(ctx->stream);
+    bis_trsv_plan_destroy(A->plan_fwd);
+    bis_trsv_plan_destroy(A->plan_bwd);
+    hipFree(A->row_ptr);
+    hipFree(A->col);
+    hipFree(A->val);
+    hipFree(A->blk_row);
+    delete A;
+    return BIS_OK;
+}
+
+bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz) {
+    if (!A) return BIS_ERR_INVALID;
+    if (n_rows) *n_rows = A->n_rows;
+    if (n_cols) *n_cols = A->n_cols;
+    if (nnz) *nnz = A->nnz;
+    return BIS_OK;
+}
+
+bis_status bis_mat_download(bis_ctx *ctx, const bis_mat *A, int64_t *row_ptr, int32_t *col,
+                            double *val) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A, "bis_mat_download: null matrix");
+    if (row_ptr) {
+        if (A->rp64) {
+            BIS_HIP_CHECK(ctx, hipMemcpyAsync(row_ptr, A->row_ptr, 8 * (size_t)(A->n_rows + 1),
+                                              hipMemcpyDeviceToHost, ctx->stream));
+            BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            std::vector<int32_t> t(A->n_rows + 1);
+            BIS_HIP_CHECK(ctx, hipMemcpyAsync(t.data(), A->row_ptr, 4 * (size_t)(A->n_rows + 1),
+                                              hipMemcpyDeviceToHost, ctx->stream));
+            BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int64_t i = 0; i <= A->n_rows; ++i) row_ptr[i] = t[i];
+        }
+    }
+    if (col && A->nnz)
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(col, A->col, 4 * (size_t)A->nnz, hipMemcpyDeviceToHost, ctx->stream));
+    if (val && A->nnz)
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(val, A->val, 8 * (size_t)A->nnz, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return BIS_OK;
+}
+
+bis_status bis_mat_gen_hpcg(bis_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int64_t row0,
+                            int64_t row1, bis_mat **out) {
+    BIS_CTX_OK(ctx);
+    const int64_t N = nx * ny * nz;
+    BIS_REQUIRE(ctx, out && nx > 0 && ny > 0 && nz > 0 && N < INT32_MAX && row0 >= 0 &&
+                         row0 <= row1 && row1 <= N,
+                "bis_mat_gen_hpcg: bad arguments");
+    const int64_t base = hpcg_row_ptr_host(row0, nx, ny, nz);
+    const int64_t nnz = hpcg_row_ptr_host(row1, nx, ny, nz) - base;
+    const int64_t n_local = row1 - row0;
+    const bool rp64 = nnz >= (int64_t)INT32_MAX - kPad;
+    bis_mat *A = nullptr;
+    bis_status st = bis_mat_alloc(ctx, n_local, N, nnz, rp64, &A);
+    if (st != BIS_OK) return st;
+    const unsigned grid = (unsigned)((n_local + 1 + 255) / 256);
+    if (rp64)
+        hipLaunchKernelGGL(gen_hpcg_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream, nx, ny,
+                           nz, row0, row1, base, (int64_t *)A->row_ptr, A->col, A->val);
+    else
+        hipLaunchKernelGGL(gen_hpcg_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, nx, ny,
+                           nz, row0, row1, base, (int32_t *)A->row_ptr, A->col, A->val);
+    if (hipGetLastError() != hipSuccess) { bis_mat_destroy(ctx, A); ctx->err = "gen_hpcg launch failed"; return BIS_ERR_HIP; }
+    st = bis_mat_finalize(ctx, A);
+    if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
+    *out = A;
+    return BIS_OK;
+}
+
+bis_status bis_mat_gen_anderson(bis_ctx *ctx, int64_t L, double t, double W, double shift,
+                                uint64_t seed, int64_t row0, int64_t row1, bis_mat **out) {
+    BIS_CTX_OK(ctx);
+    const int64_t N = L * L * L;
+    BIS_REQUIRE(ctx, out && L >= 3 && N < INT32_MAX && row0 >= 0 && row0 <= row1 && row1 <= N,
+                "bis_mat_gen_anderson: bad arguments (L >= 3)");
+    const int64_t n_local = row1 - row0, nnz = 7 * n_local;
+    const bool rp64 = nnz >= (int64_t)INT32_MAX - kPad;
+    bis_mat *A = nullptr;
+    bis_status st = bis_mat_alloc(ctx, n_local, N, nnz, rp64, &A);
+    if (st != BIS_OK) return st;
+    const unsigned grid = (unsigned)((n_local + 1 + 255) / 256);
+    if (rp64)
+        hipLaunchKernelGGL(gen_anderson_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream, L, t,
+                           W, shift, seed, row0, row1, (int64_t *)A->row_ptr, A->col, A->val);
+    else
+        hipLaunchKernelGGL(gen_anderson_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, L, t,
+                           W, shift, seed, row0, row1, (int32_t *)A->row_ptr, A->col, A->val);
+    if (hipGetLastError() != hipSuccess) { bis_mat_destroy(ctx, A); ctx->err = "gen_anderson launch failed"; return BIS_ERR_HIP; }
+    st = bis_mat_finalize(ctx, A);
+    if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
+    *out = A;
+    return BIS_OK;
+}
+
+bis_status bis_mat_split_strict(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
+                                bis_mat **U_strict, double *D, double *D_inv) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A && L_strict && U_strict, "bis_mat_split_strict: bad arguments");
+    BIS_REQUIRE(ctx, A->n_rows == A->n_cols, "bis_mat_split_strict: square local matrix required");
+    const int64_t n = A->n_rows;
+    const int n_blk = (int)((n + kSplitT - 1) / kSplitT);
+    int64_t *blk = nullptr;
+    unsigned long long *status = nullptr;
+    BIS_HIP_CHECK(ctx, hipMalloc(&blk, sizeof(int64_t) * (size_t)(2 * n_blk + 2) + 16));
+    int64_t *blk_l = blk, *blk_u = blk + n_blk, *tot = blk + 2 * n_blk;
+    status = (unsigned long long *)(ctx->scalars_dev + 32);
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0xFF, 8, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(tot, 0, 16, ctx->stream));
+    if (n_blk > 0) {
+        if (A->rp64)
+            hipLaunchKernelGGL(split_count_kernel<int64_t>, dim3(n_blk), dim3(kSplitT), 0, ctx->stream,
+                               (const int64_t *)A->row_ptr, A->col, n, (int64_t)0, blk_l, blk_u);
+        else
+            hipLaunchKernelGGL(split_count_kernel<int32_t>, dim3(n_blk), dim3(kSplitT), 0, ctx->stream,
+                               (const int32_t *)A->row_ptr, A->col, n, (int64_t)0, blk_l, blk_u);
+        hipLaunchKernelGGL(split_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, blk_l, blk_u, n_blk, tot);
+    }
+    int64_t h_tot[2] = {0, 0};
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(h_tot, tot, 16, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    bis_mat *Lm = nullptr, *Um = nullptr;
+    // strict parts of a matrix whose nnz fits int32 also fit
+    const bool rpo64 = A->rp64 && (h_tot[0] >= INT32_MAX - kPad || h_tot[1] >= INT32_MAX - kPad);
+    bis_status st = bis_mat_alloc(ctx, n, n, h_tot[0], rpo64, &Lm);
+    if (st == BIS_OK) st = bis_mat_alloc(ctx, n, n, h_tot[1], rpo64, &Um);
+    if (st != BIS_OK) { hipFree(blk); if (Lm) bis_mat_destroy(ctx, Lm); return st; }
+    if (n_blk > 0) {
+#define BIS_SPLIT_FILL(RP, RPO)                                                                  \
+    hipLaunchKernelGGL((split_fill_kernel<RP, RPO>), dim3(n_blk), dim3(kSplitT), 0, ctx->stream, \
+                       (const RP *)A->row_ptr, A->col, A->val, n, (int64_t)0, blk_l, blk_u,      \
+                       (RPO *)Lm->row_ptr, Lm->col, Lm->val, (RPO *)Um->row_ptr, Um->col,        \
+                       Um->val, D, D_inv, status)
+        if (A->rp64 && rpo64) BIS_SPLIT_FILL(int64_t, int64_t);
+        else if (A->rp64) BIS_SPLIT_FILL(int64_t, int32_t);
+        else BIS_SPLIT_FILL(int32_t, int32_t);
+#undef BIS_SPLIT_FILL
+    } else {
+        hipMemsetAsync(Lm->row_ptr, 0, rpo64 ? 8 : 4, ctx->stream);
+        hipMemsetAsync(Um->row_ptr, 0, rpo64 ? 8 : 4, ctx->stream);
+    }
+    unsigned long long h_status = 0;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h_status, status, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(blk);
+    if (h_status != ~0ull) {
+        const long long row = (long long)(h_status >> 1) - 1;
+        const bool missing = h_status & 1ull;
+        char msg[128];
+        // same texts as SanityChecker::zero_diag / no_diag (common.hpp:388-396)
+        snprintf(msg, sizeof msg, missing ? "No diagonal to extract at row index %lld"
+                                          : "Zero detected on diagonal at row index %lld", row);
+        ctx->err = msg;
+        bis_mat_destroy(ctx, Lm);
+        bis_mat_destroy(ctx, Um);
+        return missing ? BIS_ERR_NO_DIAG : BIS_ERR_ZERO_DIAG;
+    }
+    st = bis_mat_finalize(ctx, Lm);
+    if (st == BIS_OK) st = bis_mat_finalize(ctx, Um);
+    if (st != BIS_OK) { bis_mat_destroy(ctx, Lm); bis_mat_destroy(ctx, Um); return st; }
+    *L_strict = Lm;
+    *U_strict = Um;
+    return BIS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,295 @@
+// bis_sptrsv.hip -- sparse triangular solves (reference kernels.hpp:54-117,
+// serial there) and the preconditioner dispatcher built on them
+// (kernels.hpp:312-414).
+//
+// Level-scheduled, synchronisation-free solve in ONE launch:
+//   analysis (once per matrix, host): level[r] = 1 + max level of the rows r
+//     depends on; rows are stably sorted by level into perm[] so that every
+//     dependency of the row at position i sits at a position < i.
+//   solve: a persistent grid takes 256-position tickets in order from a
+//     device counter; the lane that owns a row walks that row's non-zeros in
+//     CRS storage order -- the reference's natural-order arithmetic,
+//     acc = fma(val, x[col], acc), x[r] = (b[r]-acc)/D[r], is preserved
+//     exactly -- and waits for each x[col] it needs.  Readiness travels with
+//     the data: results are published into a scratch vector pre-filled with a
+//     NaN sentinel, by ONE 8-byte agent-scope (sc1, write-through) store per
+//     row, and consumers poll exactly that word with agent-scope relaxed loads
+//     (cdna_hip_programming.md Guideline 16, form R2 "the data IS the flag").
+//     Ticket order guarantees progress: every position a waiting lane depends
+//     on belongs to a workgroup that already holds a ticket, i.e. is resident.
+//     The store sits INSIDE the wait loop so lanes of one wave that depend on
+//     each other (a level boundary inside a wave) cannot deadlock.
+//   The user-visible x is written with a plain store (nobody polls it), so x
+//   may alias b (gmres.hpp:173, gauss_seidel.hpp:37).
+//
+// HBM traffic ~ 12*nnz_T + 28*N algorithmic (+ 24*N for the sentinel scratch);
+// the solve is latency-bound on stencils (one cross-CU hand-off per level).
+#include "bis_internal.hpp"
+
+#include <algorithm>
+
+struct bis_trsv_plan {
+    int32_t *perm = nullptr; // device, rows sorted by level
+    double *xs = nullptr;    // device scratch, sentinel-filled before each solve
+    unsigned *ticket = nullptr;
+    int n_levels = 0;
+    int64_t n = 0;
+};
+
+void bis_trsv_plan_destroy(bis_trsv_plan *p) {
+    if (!p) return;
+    hipFree(p->perm);
+    hipFree(p->xs);
+    hipFree(p->ticket);
+    delete p;
+}
+
+namespace {
+
+constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload
+constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
+constexpr int kTrsvT = 256;
+
+__global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned long long *xs, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) xs[i] = kSentinel;
+}
+
+template <typename RP>
+__global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
+    const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const double *__restrict__ val, const int32_t *__restrict__ perm, int64_t n,
+    const double *__restrict__ D, const double *b, double *x, unsigned long long *xs,
+    unsigned *ticket) {
+    __shared__ unsigned s_ticket;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const unsigned t = s_ticket;
+        __syncthreads();
+        const int64_t base = (int64_t)t * kTrsvT;
+        if (base >= n) return; // every wave reaches this once tickets run out
+        const int64_t pos = base + threadIdx.x;
+        if (pos < n) {
+            const int r = perm[pos];
+            int64_t k = (int64_t)row_ptr[r];
+            const int64_t e = (int64_t)row_ptr[r + 1];
+            const double rhs = b[r], d = D[r];
+            double acc = 0.0;
+            bool done = false;
+            while (!done) {
+                while (k < e) {
+                    const unsigned long long bits = __hip_atomic_load(
+                        &xs[col[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (bits == kSentinel) break;
+                    acc = fma(val[k], __longlong_as_double((long long)bits), acc);
+                    ++k;
+                }
+                if (k == e) {
+                    const double v = (rhs - acc) / d;
+                    unsigned long long out = (unsigned long long)__double_as_longlong(v);
+                    if (v != v) out = kCanonNaN; // never publish the sentinel pattern
+                    __hip_atomic_store(&xs[r], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x[r] = __longlong_as_double((long long)out);
+                    done = true;
+                } else {
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+    }
+}
+
+// Host analysis: levels and the level-sorted permutation.
+template <typename RP>
+void build_perm(const RP *rp, const int32_t *col, int64_t n, bool backward,
+                std::vector<int32_t> &perm, int &n_levels) {
+    std::vector<int32_t> level(n, 0);
+    int maxl = 0;
+    if (!backward) {
+        for (int64_t r = 0; r < n; ++r) {
+            int l = 0;
+            for (int64_t k = rp[r]; k < rp[r + 1]; ++k) l = std::max(l, level[col[k]] + 1);
+            level[r] = l;
+            maxl = std::max(maxl, l);
+        }
+    } else {
+        for (int64_t r = n - 1; r >= 0; --r) {
+            int l = 0;
+            for (int64_t k = rp[r]; k < rp[r + 1]; ++k) l = std::max(l, level[col[k]] + 1);
+            level[r] = l;
+            maxl = std::max(maxl, l);
+        }
+    }
+    n_levels = n ? maxl + 1 : 0;
+    std::vector<int64_t> start(n_levels + 1, 0);
+    for (int64_t r = 0; r < n; ++r) start[level[r] + 1]++;
+    for (int l = 0; l < n_levels; ++l) start[l + 1] += start[l];
+    perm.resize(n);
+    for (int64_t r = 0; r < n; ++r) perm[start[level[r]]++] = (int32_t)r;
+}
+
+// Validates the triangular structure the solve relies on.
+template <typename RP>
+bool check_triangular(const RP *rp, const int32_t *col, int64_t n, bool backward) {
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+            if (col[k] < 0 || col[k] >= n) return false;
+            if (!backward && col[k] >= r) return false;
+            if (backward && col[k] <= r) return false;
+        }
+    return true;
+}
+
+bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan **out) {
+    bis_mat *M = const_cast<bis_mat *>(T);
+    bis_trsv_plan *&slot = backward ? M->plan_bwd : M->plan_fwd;
+    if (slot) { *out = slot; return BIS_OK; }
+    const int64_t n = T->n_rows;
+    std::vector<int64_t> rp(n + 1);
+    std::vector<int32_t> col((size_t)std::max<int64_t>(T->nnz, 1));
+    bis_status st = bis_mat_download(ctx, T, rp.data(), col.data(), nullptr);
+    if (st != BIS_OK) return st;
+    if (!check_triangular(rp.data(), col.data(), n, backward)) {
+        ctx->err = backward ? "bis_bsptrsv: matrix is not strictly upper triangular"
+                            : "bis_sptrsv: matrix is not strictly lower triangular";
+        return BIS_ERR_INVALID;
+    }
+    std::vector<int32_t> perm;
+    bis_trsv_plan *p = new bis_trsv_plan;
+    p->n = n;
+    build_perm(rp.data(), col.data(), n, backward, perm, p->n_levels);
+    hipError_t e = hipMalloc(&p->perm, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1));
+    if (e == hipSuccess) e = hipMalloc(&p->xs, sizeof(double) * (size_t)std::max<int64_t>(n, 1));
+    if (e == hipSuccess) e = hipMalloc(&p->ticket, sizeof(unsigned) * 4);
+    if (e == hipSuccess && n)
+        e = hipMemcpyAsync(p->perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice,
+                           ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->err = std::string("sptrsv plan: ") + hipGetErrorString(e);
+        bis_trsv_plan_destroy(p);
+        return BIS_ERR_HIP;
+    }
+    slot = p;
+    *out = p;
+    return BIS_OK;
+}
+
+bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, const double *D,
+                      const double *b) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, T && (T->n_rows == 0 || (x && D && b)), "sptrsv: bad arguments");
+    BIS_REQUIRE(ctx, T->n_rows == T->n_cols, "sptrsv: square matrix required");
+    const int64_t n = T->n_rows;
+    if (n == 0) return BIS_OK;
+    bis_trsv_plan *p = nullptr;
+    bis_status st = get_plan(ctx, T, backward, &p);
+    if (st != BIS_OK) return st;
+    const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,
+                       (unsigned long long *)p->xs, n);
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(p->ticket, 0, sizeof(unsigned), ctx->stream));
+    // persistent grid: resident by construction (<= 4 workgroups of 256 per CU)
+    const int64_t n_tickets = (n + kTrsvT - 1) / kTrsvT;
+    const int grid = (int)std::min<int64_t>(n_tickets, (int64_t)ctx->n_cus * 4);
+    if (T->rp64)
+        hipLaunchKernelGGL(sptrsv_syncfree_kernel<int64_t>, dim3(grid), dim3(kTrsvT), 0, ctx->stream,
+                           (const int64_t *)T->row_ptr, T->col, T->val, p->perm, n, D, b, x,
+                           (unsigned long long *)p->xs, p->ticket);
+    else
+        hipLaunchKernelGGL(sptrsv_syncfree_kernel<int32_t>, dim3(grid), dim3(kTrsvT), 0, ctx->stream,
+                           (const int32_t *)T->row_ptr, T->col, T->val, p->perm, n, D, b, x,
+                           (unsigned long long *)p->xs, p->ticket);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+bis_status bis_sptrsv(bis_ctx *ctx, const bis_mat *L_strict, double *x, const double *D,
+                      const double *b) {
+    return trsv_solve(ctx, L_strict, false, x, D, b);
+}
+
+bis_status bis_bsptrsv(bis_ctx *ctx, const bis_mat *U_strict, double *x, const double *D,
+                       const double *b) {
+    return trsv_solve(ctx, U_strict, true, x, D, b);
+}
+
+// two_stage_gauss_seidel, kernels.hpp:312-333.
+bis_status bis_two_stage_gauss_seidel(bis_ctx *ctx, const bis_mat *strict, double *tmp,
+                                      double *work, const double *D_inv, const double *input,
+                                      double *output, int64_t n, int inner_iters) {
+    BIS_CTX_OK(ctx);
+    bis_status st = bis_elemwise_mult_vectors(ctx, work, D_inv, input, n, 1.0);   // :317
+    if (st == BIS_OK) st = bis_copy_vector(ctx, output, work, n);                  // :319
+    for (int inner = 1; st == BIS_OK && inner <= inner_iters; ++inner) {
+        st = bis_spmv(ctx, strict, work, tmp);                                     // :323
+        if (st == BIS_OK) st = bis_elemwise_mult_vectors(ctx, tmp, D_inv, tmp, n, -1.0); // :325
+        std::swap(work, tmp);                                                      // :327
+        if (st == BIS_OK) st = bis_sum_vectors(ctx, output, output, work, n, 1.0); // :331
+    }
+    return st;
+}
+
+// apply_preconditioner, kernels.hpp:336-414.
+bis_status bis_apply_preconditioner(bis_ctx *ctx, int pc, int64_t n, const bis_mat *L_strict,
+                                    const bis_mat *U_strict, const double *A_D,
+                                    const double *A_D_inv, const double *L_D, const double *U_D,
+                                    double *output, double *input, double *tmp, double *work,
+                                    int outer_iters, int inner_iters) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && outer_iters >= 1, "bis_apply_preconditioner: bad arguments");
+    double *input_storage = nullptr;
+    bis_status st = BIS_OK;
+    if (outer_iters > 1) { // :348-352 (the one place the reference allocates in a kernel)
+        st = bis_vec_alloc(ctx, n, &input_storage);
+        if (st == BIS_OK) st = bis_copy_vector(ctx, input_storage, input, n);
+    }
+    for (int i = 0; st == BIS_OK && i < outer_iters; ++i) {
+        switch (pc) {
+        case BIS_PC_JACOBI:
+            st = bis_elemwise_div_vectors(ctx, output, input, A_D, n, 1.0);        // :357
+            break;
+        case BIS_PC_GAUSS_SEIDEL:
+            st = bis_sptrsv(ctx, L_strict, output, A_D, input);                    // :359
+            break;
+        case BIS_PC_BACKWARDS_GAUSS_SEIDEL:
+            st = bis_bsptrsv(ctx, U_strict, output, A_D, input);                   // :361
+            break;
+        case BIS_PC_SYMMETRIC_GAUSS_SEIDEL:
+            st = bis_sptrsv(ctx, L_strict, tmp, A_D, input);                       // :365
+            if (st == BIS_OK) st = bis_elemwise_mult_vectors(ctx, tmp, tmp, A_D, n, 1.0); // :369
+            if (st == BIS_OK) st = bis_bsptrsv(ctx, U_strict, output, A_D, tmp);   // :373
+            break;
+        case BIS_PC_TWO_STAGE_GS:
+            st = bis_two_stage_gauss_seidel(ctx, L_strict, tmp, work, A_D_inv, input, output, n,
+                                            inner_iters);                          // :376
+            break;
+        case BIS_PC_SYMMETRIC_TWO_STAGE_GS:
+            st = bis_two_stage_gauss_seidel(ctx, L_strict, tmp, work, A_D_inv, input, output, n,
+                                            inner_iters);                          // :379
+            if (st == BIS_OK) st = bis_elemwise_mult_vectors(ctx, output, output, A_D, n, 1.0); // :382
+            if (st == BIS_OK)
+                st = bis_two_stage_gauss_seidel(ctx, U_strict, tmp, work, A_D_inv, output, output,
+                                                n, inner_iters);                   // :384
+            break;
+        case BIS_PC_ILU0:
+            st = bis_sptrsv(ctx, L_strict, tmp, L_D, input);                       // :390
+            if (st == BIS_OK) st = bis_bsptrsv(ctx, U_strict, output, U_D, tmp);   // :394
+            break;
+        default:
+            st = bis_copy_vector(ctx, output, input, n);                           // :398
+        }
+        if (st == BIS_OK && outer_iters > 1 && i != outer_iters - 1)
+            st = bis_copy_vector(ctx, input, output, n);                           // :401-403
+    }
+    if (st == BIS_OK && outer_iters > 1) st = bis_copy_vector(ctx, input, input_storage, n); // :406-408
+    if (input_storage) bis_vec_free(ctx, input_storage);
+    return st;
+}
+
+} // extern "C"

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/s (+ SpMV GFLOP/s and % of the HBM roofline) on
+the HPCG 27-point operator, the metric BASELINE.json names.
+
+    python bench.py --gpus N --steps K --warmup W [--size 256] [--precond none|j]
+
+A "step" is one CG iteration (methods/cg.hpp:6-54 + the residual sample of
+:162-166) on synthetic HPCG-`size` (size^3 rows, 27-point, b = 1, x0 = 0.1),
+generated directly in HBM; inputs are resident before the timed region.
+N > 1: one process per GPU (torch.distributed.run), the matrix 1-D
+row-partitioned (z-slabs), strong scaling: the global problem is fixed.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (CRS
+SpMV) with HIP events recorded on the library's stream inside the timed
+region; `cpu_baseline` times the oracle's OpenMP port of the same CG loop on
+the host cores for a bounded number of iterations (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=256, help="HPCG grid edge (256 = metric size)")
+    ap.add_argument("--precond", default="none", choices=["none", "j"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="0: sized for ~10-30 s")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "spmv_traffic.json"),
+                    help="per-launch HBM bytes from the rocprofv3 PMC passes, if collected")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, precond, iters):
+    """Oracle (OpenMP port of the reference's CG loop) on the host cores."""
+    from oracle.pyoracle import Oracle
+    cores = os.cpu_count() or 1
+    threads = int(os.environ.get("BIS_CPU_THREADS", min(cores, 64)))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    orc = Oracle()
+    t0 = time.time()
+    A = orc.gen_hpcg(size)
+    gen_s = time.time() - t0
+    import numpy as np
+    D = np.full(A.n_rows, 26.0) if precond == "j" else None
+    if iters <= 0:
+        # one probe iteration, then size the sample for ~15 s of CPU work
+        _, s1 = orc.cg_run(A, 1, D)
+        iters = int(max(3, min(200, 15.0 / max(s1, 1e-3))))
+    hist, secs = orc.cg_run(A, iters, D)
+    return dict(value=iters / secs, unit="CG iterations/s", cores=orc.num_threads(), kind="port",
+                sample=f"HPCG {size}^3 ({A.nnz} nnz), {iters} CG iterations of the oracle's OpenMP "
+                       f"port (oracle/bis_oracle.c orc_cg_run), {orc.num_threads()} threads, "
+                       f"matrix generated on host in {gen_s:.1f} s",
+                ms_per_step=1e3 * secs / iters), hist
+
+
+def main():
+    args = parse()
+    import torch  # plumbing: device sync + torch.distributed launcher contract
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
+                             "(one process per GPU)")
+    torch.cuda.set_device(local_rank)
+
+    from basic_iterative_solvers_amd import Context
+
+    if world > 1:
+        from basic_iterative_solvers_amd.dist_bench import run_distributed
+        return run_distributed(args, rank, world, local_rank)
+
+    ctx = Context(local_rank)
+    n1 = args.size
+    N = n1 ** 3
+    A = ctx.gen_hpcg(n1)
+    nnz = A.nnz
+    b, x = ctx.alloc(N), ctx.alloc(N)
+    ctx.init_vector(b, 1.0)
+    ctx.init_vector(x, 0.1)
+    D = None
+    if args.precond == "j":
+        D = ctx.alloc(N)
+        ctx.init_vector(D, 26.0)
+    cg = ctx.cg(A, b, x, D)
+    r0 = cg.init(0.0)  # tol 0: the timed iterations all execute (no early stop)
+    cg.iterate(args.warmup)
+    ctx.sync()
+    torch.cuda.synchronize()
+
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    cg.iterate(args.steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ctx.profile(False)
+    launches, spmv_ms = ctx.profile_read()
+    iters, conv, hist = cg.status(hist_cap=args.warmup + args.steps + 1)
+    if iters != args.warmup + args.steps:
+        raise SystemExit(f"timed region invalid: {iters} iterations executed, "
+                         f"expected {args.warmup + args.steps}")
+    secs = t1 - t0
+    its = args.steps / secs
+
+    spmv_bytes = 12 * nnz + 20 * N
+    spmv_avg_s = spmv_ms * 1e-3 / max(launches, 1)
+    achieved = spmv_bytes / spmv_avg_s / 1e9
+    traffic = None
+    if os.path.exists(args.traffic_json):
+        try:
+            tj = json.load(open(args.traffic_json))
+            if tj.get("size") == n1:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    fused_bytes = 12 * nnz + (108 if args.precond == "j" else 92) * N
+    out = {
+        "metric": "CG iterations/sec + SpMV GFLOP/s (% HBM roofline), HPCG 256^3 at 1/2/4/8 GPUs",
+        "value": its, "unit": "CG iterations/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"HPCG {n1}^3 27-point, -cg" +
+                               (" -p j" if args.precond == "j" else "") +
+                               ", b=1 x0=0.1, fused device schedule", "rows": N, "nnz": nnz,
+                   "partition": "1 GPU"},
+        "spmv_gflops": 2.0 * nnz / spmv_avg_s / 1e9,
+        "cg_effective_GBs": fused_bytes * its / 1e9,
+        "residual_r0": r0, "residual_last": float(hist[-1]),
+        "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": spmv_bytes,
+                     "avg_launch_ms": spmv_avg_s * 1e3, "launches": launches},
+    }
+    if not args.no_cpu_baseline:
+        cb, cpu_hist = cpu_baseline(n1, args.precond, args.cpu_iters)
+        out["cpu_baseline"] = cb
+        # parity of the timed run against the CPU path on the same input
+        m = min(len(cpu_hist), len(hist))
+        import numpy as np
+        out["parity_max_dr_over_r0"] = float(np.max(np.abs(cpu_hist[:m] - hist[:m])) / cpu_hist[0])
+    print(json.dumps(out), flush=True)
+    cg.free()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,260 @@
+/*
+ * bis_hip.h -- C ABI of the MI355X (gfx950) implementation of the
+ * SpMV + preconditioner-apply + BLAS-1 hot path of
+ * DanecLacey/basic_iterative_solvers.
+ *
+ * This is the drop-in boundary: every entry point replaces one free function
+ * of the reference's operator surface (kernels.hpp / sparse_matrix.hpp /
+ * methods/jacobi.hpp) or one step of its accelerator plugin protocol (the
+ * SMAX seam: utilities/smax_helpers.hpp, kernels.hpp:44-52).  The reference
+ * interface each function replaces is cited as file:line relative to the
+ * reference tree.  Signatures are plain C: opaque handles, raw device
+ * pointers (`double *` obtained from bis_vec_alloc, exactly where the
+ * reference passes `double *` from `new double[N]`), sizes and scalars.
+ * No C++/torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns a bis_status (0 = BIS_OK); bis_last_error()
+ *     gives the message.  The C++ host layer (basic_iterative_solvers_amd/
+ *     host/) restores the reference's `void` + exit(EXIT_FAILURE) convention
+ *     (common.hpp:382-396).
+ *   - one host thread per context; kernels are ordered on the context's HIP
+ *     stream; only functions that return a host scalar (bis_dot,
+ *     bis_euclidean_vec_norm, downloads, bis_sync) block.
+ *   - vector arguments may alias exactly where the reference's callers alias
+ *     them: result==operand for the elementwise
+ *     kernels, x==b for the triangular solves, output==input for
+ *     bis_apply_preconditioner.
+ *   - there is NO CPU fallback: if no gfx950 device is usable the context
+ *     cannot be created and every entry point fails with BIS_ERR_NO_DEVICE.
+ */
+#ifndef BIS_HIP_H
+#define BIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BIS_API __attribute__((visibility("default")))
+
+typedef int bis_status;
+enum {
+    BIS_OK = 0,
+    BIS_ERR_NO_DEVICE = 1,   /* no usable HIP device / context missing */
+    BIS_ERR_INVALID = 2,     /* bad argument (null handle, negative size ...) */
+    BIS_ERR_HIP = 3,         /* a HIP runtime call failed */
+    BIS_ERR_ZERO_DIAG = 4,   /* SanityChecker::zero_diag, common.hpp:388-391 */
+    BIS_ERR_NO_DIAG = 5,     /* SanityChecker::no_diag,   common.hpp:393-396 */
+    BIS_ERR_UNSUPPORTED = 6, /* e.g. a row longer than the kernel supports */
+    BIS_ERR_COMM = 7         /* RCCL / halo-exchange failure */
+};
+
+/* PrecondType, common.hpp:38-47 (same ordinals). */
+enum {
+    BIS_PC_NONE = 0,
+    BIS_PC_JACOBI = 1,
+    BIS_PC_GAUSS_SEIDEL = 2,
+    BIS_PC_BACKWARDS_GAUSS_SEIDEL = 3,
+    BIS_PC_SYMMETRIC_GAUSS_SEIDEL = 4,
+    BIS_PC_TWO_STAGE_GS = 5,
+    BIS_PC_SYMMETRIC_TWO_STAGE_GS = 6,
+    BIS_PC_ILU0 = 7
+};
+
+typedef struct bis_ctx bis_ctx; /* device + stream + scratch (SMAX::Interface
+                                   role, preprocessing.hpp:52-65) */
+typedef struct bis_mat bis_mat; /* device-resident MatrixCRS,
+                                   sparse_matrix.hpp:59-179 */
+
+/* ---- context ------------------------------------------------------------ */
+/* `stream` is a hipStream_t to run on (NULL: the context creates its own). */
+BIS_API bis_status bis_ctx_create(int device, void *stream, bis_ctx **out);
+BIS_API bis_status bis_ctx_destroy(bis_ctx *ctx);
+BIS_API const char *bis_last_error(const bis_ctx *ctx);
+BIS_API bis_status bis_sync(bis_ctx *ctx);
+BIS_API void *bis_ctx_stream(bis_ctx *ctx);
+/* "gfx950", CU count, HBM bytes -- for logs and the bench JSON. */
+BIS_API bis_status bis_device_info(bis_ctx *ctx, char *arch, size_t arch_len,
+                                   int *n_cus, int64_t *hbm_bytes);
+/* number of exported kernel-level symbols, for the load test */
+BIS_API int bis_abi_version(void);
+
+/* ---- vectors: replaces `new double[N]` / delete[] in Solver::
+ * allocate_structs (solver.hpp:82-110, :130-145) --------------------------- */
+BIS_API bis_status bis_vec_alloc(bis_ctx *ctx, int64_t n, double **out);
+BIS_API bis_status bis_vec_free(bis_ctx *ctx, double *v);
+BIS_API bis_status bis_vec_upload(bis_ctx *ctx, double *dst_dev,
+                                  const double *src_host, int64_t n);
+BIS_API bis_status bis_vec_download(bis_ctx *ctx, double *dst_host,
+                                    const double *src_dev, int64_t n);
+
+/* ---- matrices ------------------------------------------------------------ */
+/* MatrixCRS(n_rows, n_cols, nnz) + array fill (sparse_matrix.hpp:76-89) and
+ * SMAX register_A (smax_helpers.hpp:10-11): uploads host CRS arrays exactly
+ * as given (int32 row_ptr/col, fp64 val, arbitrary column order inside a
+ * row) and builds the row-block metadata the SpMV kernel uses. */
+BIS_API bis_status bis_mat_create(bis_ctx *ctx, int64_t n_rows, int64_t n_cols,
+                                  int64_t nnz, const int32_t *row_ptr,
+                                  const int32_t *col, const double *val,
+                                  bis_mat **out);
+/* Same with 64-bit row pointers (nnz >= 2^31, e.g. HPCG-512: SURVEY.md
+ * section 5 defect 6 -- not representable in the reference's MatrixCRS). */
+BIS_API bis_status bis_mat_create64(bis_ctx *ctx, int64_t n_rows,
+                                    int64_t n_cols, int64_t nnz,
+                                    const int64_t *row_ptr, const int32_t *col,
+                                    const double *val, bis_mat **out);
+BIS_API bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A);
+BIS_API bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows,
+                                int64_t *n_cols, int64_t *nnz);
+/* copy the device CRS back (tests: bit-exact CRS checks); any pointer may be
+ * NULL.  row_ptr is returned as int64. */
+BIS_API bis_status bis_mat_download(bis_ctx *ctx, const bis_mat *A,
+                                    int64_t *row_ptr, int32_t *col,
+                                    double *val);
+
+/* Synthetic inputs generated directly in HBM (stands in
+ * for MatrixCOO::scamac_generate, sparse_matrix.hpp:577-721, and for reading
+ * HPCG-n.mtx).  Rows [row0,row1) of the global matrix with GLOBAL column
+ * indices; n_cols = global row count.
+ *   HPCG: 27-point, a_ii=26, a_ij=-1, open boundaries, ascending columns.
+ *   Anderson: 7-point periodic L^3, off-diagonals -t, diagonal
+ *   W*(u(seed,row)-1/2)+shift, ascending columns. */
+BIS_API bis_status bis_mat_gen_hpcg(bis_ctx *ctx, int64_t nx, int64_t ny,
+                                    int64_t nz, int64_t row0, int64_t row1,
+                                    bis_mat **out);
+BIS_API bis_status bis_mat_gen_anderson(bis_ctx *ctx, int64_t L, double t,
+                                        double W, double shift, uint64_t seed,
+                                        int64_t row0, int64_t row1,
+                                        bis_mat **out);
+
+/* Setup steps kept on the device:
+ * split_LU (utilities/LU_factors.hpp:122-309): strict lower / strict upper
+ * parts of A, row order preserved; and the diagonal extraction of
+ * peel_diag_crs (:827-869): D and 1/D.  Fails with BIS_ERR_ZERO_DIAG /
+ * BIS_ERR_NO_DIAG like the reference's SanityChecker. */
+BIS_API bis_status bis_mat_split_strict(bis_ctx *ctx, const bis_mat *A,
+                                        bis_mat **L_strict, bis_mat **U_strict,
+                                        double *D, double *D_inv);
+
+/* ---- the operator surface (kernels.hpp) ------------------------------------ */
+/* spmv / native_spmv, kernels.hpp:22-52: y = A x. */
+BIS_API bis_status bis_spmv(bis_ctx *ctx, const bis_mat *A, const double *x,
+                            double *y);
+/* sptrsv / native_sptrsv, kernels.hpp:54-86: x = (D + L_strict)^-1 b,
+ * natural row order arithmetic; x may alias b. */
+BIS_API bis_status bis_sptrsv(bis_ctx *ctx, const bis_mat *L_strict, double *x,
+                              const double *D, const double *b);
+/* bsptrsv / native_bsptrsv, kernels.hpp:88-117: x = (D + U_strict)^-1 b. */
+BIS_API bis_status bis_bsptrsv(bis_ctx *ctx, const bis_mat *U_strict,
+                               double *x, const double *D, const double *b);
+/* subtract_vectors, kernels.hpp:119-126: r = a - scale*b. */
+BIS_API bis_status bis_subtract_vectors(bis_ctx *ctx, double *r,
+                                        const double *a, const double *b,
+                                        int64_t n, double scale);
+/* sum_vectors, kernels.hpp:128-135: r = a + scale*b. */
+BIS_API bis_status bis_sum_vectors(bis_ctx *ctx, double *r, const double *a,
+                                   const double *b, int64_t n, double scale);
+/* elemwise_mult_vectors, kernels.hpp:137-144: r = a*scale*b. */
+BIS_API bis_status bis_elemwise_mult_vectors(bis_ctx *ctx, double *r,
+                                             const double *a, const double *b,
+                                             int64_t n, double scale);
+/* elemwise_div_vectors, kernels.hpp:146-153: r = a/(scale*b). */
+BIS_API bis_status bis_elemwise_div_vectors(bis_ctx *ctx, double *r,
+                                            const double *a, const double *b,
+                                            int64_t n, double scale);
+/* compute_residual, kernels.hpp:155-162: tmp = A x; res = b - tmp. */
+BIS_API bis_status bis_compute_residual(bis_ctx *ctx, const bis_mat *A,
+                                        const double *x, const double *b,
+                                        double *res, double *tmp);
+/* euclidean_vec_norm, kernels.hpp:194-203 (blocking, host result). */
+BIS_API bis_status bis_euclidean_vec_norm(bis_ctx *ctx, const double *v,
+                                          int64_t n, double *result_host);
+/* dot, kernels.hpp:205-212 (blocking, host result). */
+BIS_API bis_status bis_dot(bis_ctx *ctx, const double *a, const double *b,
+                           int64_t n, double *result_host);
+/* stream-ordered variants: the scalar stays on the device (sum of squares,
+ * not its root, for the norm) -- for fused / multi-GPU schedules. */
+BIS_API bis_status bis_dot_dev(bis_ctx *ctx, const double *a, const double *b,
+                               int64_t n, double *result_dev);
+BIS_API bis_status bis_sumsq_dev(bis_ctx *ctx, const double *v, int64_t n,
+                                 double *result_dev);
+/* scale, kernels.hpp:214-220: r = v*scalar. */
+BIS_API bis_status bis_scale(bis_ctx *ctx, double *r, const double *v,
+                             double scalar, int64_t n);
+/* init_vector, kernels.hpp:236-241. */
+BIS_API bis_status bis_init_vector(bis_ctx *ctx, double *v, double val,
+                                   int64_t n);
+/* copy_vector, kernels.hpp:252-257. */
+BIS_API bis_status bis_copy_vector(bis_ctx *ctx, double *out, const double *in,
+                                   int64_t n);
+/* normalize_x, methods/jacobi.hpp:27-40:
+ * x_new = (b - (x_new - D*x_old))/D. */
+BIS_API bis_status bis_normalize_x(bis_ctx *ctx, double *x_new,
+                                   const double *x_old, const double *D,
+                                   const double *b, int64_t n);
+/* dgemm_transpose1 as used at gmres.hpp:358 (kernels.hpp:259-271 with
+ * n_cols_B = 1): out[i] = sum_{k<n_vec} V[k*ldv+i]*y[k]; y is a HOST array of
+ * n_vec (<= 64) coefficients.  (The reference reads y[n_vec] one past the
+ * end at a restart; the defined semantics is that term = 0.) */
+BIS_API bis_status bis_multi_axpy(bis_ctx *ctx, const double *V, int64_t ldv,
+                                  const double *y_host, int n_vec, double *out,
+                                  int64_t n);
+/* two_stage_gauss_seidel, kernels.hpp:312-333 (inner_iters =
+ * PRECOND_INNER_ITERS). */
+BIS_API bis_status bis_two_stage_gauss_seidel(bis_ctx *ctx,
+                                              const bis_mat *strict,
+                                              double *tmp, double *work,
+                                              const double *D_inv,
+                                              const double *input,
+                                              double *output, int64_t n,
+                                              int inner_iters);
+/* apply_preconditioner, kernels.hpp:336-414: output = M^-1 input
+ * (outer_iters = PRECOND_OUTER_ITERS, inner_iters = PRECOND_INNER_ITERS). */
+BIS_API bis_status bis_apply_preconditioner(
+    bis_ctx *ctx, int precond_type, int64_t n, const bis_mat *L_strict,
+    const bis_mat *U_strict, const double *A_D, const double *A_D_inv,
+    const double *L_D, const double *U_D, double *output, double *input,
+    double *tmp, double *work, int outer_iters, int inner_iters);
+
+/* ---- fused CG schedule (cg.hpp:6-54 + :162-166, same arithmetic, fewer
+ * passes; SURVEY.md section 8d "fused lower bound") -------------------------- */
+typedef struct bis_cg bis_cg;
+/* Binds the operands of one CG solve: A, optional Jacobi diagonal (NULL: no
+ * preconditioner), b, and x (in/out: x_0 on entry).  Owns p, r, z, tmp. */
+BIS_API bis_status bis_cg_create(bis_ctx *ctx, const bis_mat *A,
+                                 const double *A_D, const double *b, double *x,
+                                 bis_cg **out);
+BIS_API bis_status bis_cg_destroy(bis_ctx *ctx, bis_cg *cg);
+/* init_residual (cg.hpp:100-118) + init_stopping_criteria (solver.hpp:173):
+ * r0 = b - A x0, z0 = M^-1 r0, p0 = z0; returns ||r0||_2 (blocking). */
+BIS_API bis_status bis_cg_init(bis_ctx *ctx, bis_cg *cg, double tol,
+                               double *r0_norm_host);
+/* Runs up to `n_iters` iterations stream-ordered, no host round trip inside:
+ * alpha/beta stay on the device, the stopping test of solver.hpp:177-192
+ * (converged | NaN/inf) is evaluated on the device after every iteration and
+ * later iterations become no-ops once it fires.  Residual norms are appended
+ * to the solve's device history.  Non-blocking. */
+BIS_API bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters);
+/* Blocking: iterations actually performed so far, converged flag, and the
+ * residual history (||r_0||..||r_k||, k = iterations) copied to hist_host
+ * (capacity hist_cap doubles; may be NULL). */
+BIS_API bis_status bis_cg_status(bis_ctx *ctx, bis_cg *cg, int *iters,
+                                 int *converged, double *hist_host,
+                                 int hist_cap);
+
+/* ---- measurement ------------------------------------------------------------ */
+/* HIP-event timing of the kernels launched on the context's stream.  While
+ * enabled, each bis_spmv launch (and the SpMV inside bis_cg_iterate) is
+ * bracketed by a hipEvent pair; bis_profile_read returns launches and the
+ * summed duration in milliseconds and resets the counters (blocking). */
+BIS_API bis_status bis_profile_enable(bis_ctx *ctx, int on);
+BIS_API bis_status bis_profile_read(bis_ctx *ctx, int64_t *spmv_launches,
+                                    double *spmv_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIS_HIP_H */

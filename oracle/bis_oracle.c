@@ -1121,3 +1121,53 @@ ORC_API int orc_solve(int64_t n_rows, int64_t nnz, const int64_t *row_ptr,
     free(L_val); free(Ls_val); free(U_val); free(Us_val);
     return rc;
 }
+
+/* ------------------------------------------------------------------------ */
+/* cpu_baseline leg of bench.py: the unpreconditioned / Jacobi CG loop of     */
+/* methods/cg.hpp:6-54 + :162-166 on a caller-owned CRS, without the setup   */
+/* copies of orc_solve (an HPCG-256 matrix is 5.4 GB).  Runs `iters`          */
+/* iterations (no stopping test), returns the residual norms in hist[0..iters]*/
+/* and the wall time of the iteration loop alone in *loop_seconds.            */
+/* ------------------------------------------------------------------------ */
+#include <sys/time.h>
+static double wall_now(void) {
+    struct timeval tv;
+    gettimeofday(&tv, 0);
+    return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+ORC_API int orc_cg_run(int64_t n, const int64_t *row_ptr, const int32_t *col,
+                       const double *val, const double *A_D, double b_val,
+                       double x0_val, int iters, double *hist,
+                       double *loop_seconds) {
+    double *x = dalloc(n), *xn = dalloc(n), *b = dalloc(n), *tmp = dalloc(n),
+           *p = dalloc(n), *pn = dalloc(n), *r = dalloc(n), *rn = dalloc(n),
+           *z = dalloc(n), *zn = dalloc(n);
+    orc_init_vector(x, x0_val, n);
+    orc_init_vector(b, b_val, n);
+    orc_init_vector(xn, 0.0, n); orc_init_vector(tmp, 0.0, n);
+    orc_init_vector(p, 0.0, n); orc_init_vector(pn, 0.0, n);
+    orc_init_vector(r, 0.0, n); orc_init_vector(rn, 0.0, n);
+    orc_init_vector(z, 0.0, n); orc_init_vector(zn, 0.0, n);
+    orc_spmv(n, row_ptr, col, val, x, tmp);
+    orc_subtract_vectors(r, b, tmp, n, 1.0);
+    if (A_D) orc_elemwise_div_vectors(z, r, A_D, n, 1.0); else orc_copy_vector(z, r, n);
+    orc_copy_vector(p, z, n);
+    hist[0] = orc_euclidean_vec_norm(r, n);
+    double t0 = wall_now();
+    for (int it = 0; it < iters; ++it) {
+        orc_spmv(n, row_ptr, col, val, p, tmp);
+        double tmp_dot = orc_dot(r, z, n);
+        double alpha = tmp_dot / orc_dot(tmp, p, n);
+        orc_sum_vectors(xn, x, p, n, alpha);
+        orc_subtract_vectors(rn, r, tmp, n, alpha);
+        if (A_D) orc_elemwise_div_vectors(zn, rn, A_D, n, 1.0); else orc_copy_vector(zn, rn, n);
+        double beta = orc_dot(rn, zn, n) / tmp_dot;
+        orc_sum_vectors(pn, zn, p, n, beta);
+        hist[it + 1] = orc_euclidean_vec_norm(rn, n);
+        swapd(&p, &pn); swapd(&z, &zn); swapd(&r, &rn); swapd(&x, &xn);
+    }
+    *loop_seconds = wall_now() - t0;
+    free(x); free(xn); free(b); free(tmp); free(p); free(pn); free(r); free(rn);
+    free(z); free(zn);
+    return 0;
+}

@@ -299,6 +299,16 @@ class Oracle:
                                   col.ctypes, val.ctypes)
         return CRS(n, rp, col, val, n_cols=N)
 
+    def cg_run(self, A, iters, A_D=None, b_val=1.0, x0_val=0.1):
+        """Plain CG loop for bench.py's cpu_baseline; returns (hist, seconds)."""
+        hist = np.zeros(iters + 1)
+        secs = C.c_double()
+        self.lib.orc_cg_run(C.c_int64(A.n_rows), A.row_ptr.ctypes, A.col.ctypes,
+                            A.val.ctypes, A_D.ctypes if A_D is not None else None,
+                            C.c_double(b_val), C.c_double(x0_val), C.c_int(iters),
+                            hist.ctypes, C.byref(secs))
+        return hist, secs.value
+
     # ---- full solve --------------------------------------------------------
     def solve(self, A, solver, precond="none", max_iters=1000, tol=1e-14,
               restart_len=10, outer=1, inner=0, init_x=0.1, b_val=1.0,

@@ -1,0 +1,312 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against
+the oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (GOLDEN, GOLDEN_MATS, check_history, crs_of, load_golden,
+                     load_histories, parse_hist_key, relerr)
+from oracle.pyoracle import CRS
+
+pytestmark = pytest.mark.gpu
+
+KTOL = 1e-13  # kernel-level relative tolerance, SURVEY.md 8d
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from basic_iterative_solvers_amd import Context
+    c = Context()
+    info = c.device_info()
+    assert info["arch"].startswith("gfx950")
+    yield c
+    c.close()
+
+
+def dev_spmv(ctx, A, x):
+    dA = ctx.matrix(A)
+    dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
+    ctx.spmv(dA, dx, dy)
+    y = dy.to_host()
+    dA.free(); dx.free(); dy.free()
+    return y
+
+
+@pytest.mark.parametrize("name", GOLDEN_MATS)
+def test_kernels_vs_reference_golden(ctx, name):
+    g = load_golden(name)
+    A, Ls, Us = crs_of(g, "A"), crs_of(g, "Ls"), crs_of(g, "Us")
+    n = A.n_rows
+    x, y, D, Dinv = g["x"], g["y"], g["A_D"], g["A_D_inv"]
+    dA, dLs, dUs = ctx.matrix(A), ctx.matrix(Ls), ctx.matrix(Us)
+    dx, dy, dD, dDinv = ctx.upload(x), ctx.upload(y), ctx.upload(D), ctx.upload(Dinv)
+    out, tmp, work = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    ones = ctx.upload(np.ones(n))
+
+    ctx.spmv(dA, dx, out)
+    assert relerr(out.to_host(), g["spmv"]) <= KTOL
+    ctx.sptrsv(dLs, out, dD, dy)
+    assert relerr(out.to_host(), g["sptrsv"]) <= KTOL
+    ctx.bsptrsv(dUs, out, dD, dy)
+    assert relerr(out.to_host(), g["bsptrsv"]) <= KTOL
+    ctx.copy_vector(out, dy)
+    ctx.sptrsv(dLs, out, dD, out)  # x aliases b (gmres.hpp:173)
+    assert relerr(out.to_host(), g["sptrsv_inplace"]) <= KTOL
+
+    # elementwise: bit-exact with the compiled reference
+    ctx.subtract_vectors(out, dx, dy, 0.37)
+    assert np.array_equal(out.to_host(), g["sub"])
+    ctx.sum_vectors(out, dx, dy, -1.25)
+    assert np.array_equal(out.to_host(), g["sum"])
+    ctx.elemwise_mult_vectors(out, dx, dy, -1.0)
+    assert np.array_equal(out.to_host(), g["mul"])
+    ctx.elemwise_div_vectors(out, dx, dD, 1.0)
+    assert np.array_equal(out.to_host(), g["div"])
+    ctx.scale(out, dx, 1.0 / 3.0)
+    assert np.array_equal(out.to_host(), g["scale_vec"])
+    ctx.copy_vector(out, dx)
+    assert np.array_equal(out.to_host(), x)
+    ctx.init_vector(out, 0.1)
+    assert np.array_equal(out.to_host(), np.full(n, 0.1))
+    # aliasing: result == operand (gauss_seidel.hpp:34, kernels.hpp:325,369)
+    ctx.copy_vector(out, dy)
+    ctx.subtract_vectors(out, dx, out, 0.37)
+    assert np.array_equal(out.to_host(), g["sub"])
+    ctx.copy_vector(out, dx)
+    ctx.elemwise_mult_vectors(out, out, dy, -1.0)
+    assert np.array_equal(out.to_host(), g["mul"])
+
+    assert abs(ctx.dot(dx, dy) - g["dot"][0]) <= KTOL * np.abs(x).dot(np.abs(y))
+    assert abs(ctx.euclidean_vec_norm(dx) - g["norm"][0]) <= KTOL * g["norm"][0]
+    ctx.compute_residual(dA, dx, dy, out, tmp)
+    assert relerr(out.to_host(), g["residual"]) <= KTOL
+    xn = ctx.upload(g["spmv"])
+    ctx.normalize_x(xn, dx, dD, dy)
+    assert relerr(xn.to_host(), g["normalize_x"]) <= KTOL
+
+    for pc in ("none", "j", "gs", "bgs", "sgs", "2st", "s2st"):
+        inp = ctx.upload(y)
+        ctx.apply_preconditioner(pc, n, dLs, dUs, dD, dDinv, ones, ones, out, inp, tmp, work)
+        assert relerr(out.to_host(), g["pc_" + pc]) <= KTOL, pc
+        assert np.array_equal(inp.to_host(), y)  # input untouched
+        inp.free()
+    inp = ctx.upload(y)
+    ctx.apply_preconditioner("gs", n, dLs, dUs, dD, dDinv, ones, ones, inp, inp, tmp, work)
+    assert relerr(inp.to_host(), g["pc_gs_inplace"]) <= KTOL
+    for pc in ("j", "gs", "sgs", "2st", "s2st"):  # PRECOND_OUTER_ITERS=2, INNER=2
+        inp.set(y)
+        ctx.apply_preconditioner(pc, n, dLs, dUs, dD, dDinv, ones, ones, out, inp, tmp, work,
+                                 outer=2, inner=2)
+        assert relerr(out.to_host(), g["pc22_" + pc]) <= 1e-12, pc
+        assert np.array_equal(inp.to_host(), y)
+    # ILU(0) apply with the reference's own factors
+    iLs, iUs = ctx.matrix(crs_of(g, "iluLs")), ctx.matrix(crs_of(g, "iluUs"))
+    iLD, iUD = ctx.upload(g["iluLD"]), ctx.upload(g["iluUD"])
+    inp.set(y)
+    ctx.apply_preconditioner("ilu0", n, iLs, iUs, dD, dDinv, iLD, iUD, out, inp, tmp, work)
+    assert relerr(out.to_host(), g["pc_ilu0"]) <= 1e-12
+
+    V = ctx.upload(g["V"].ravel())
+    ctx.multi_axpy(V, n, g["yy"], 5, out, n)
+    assert relerr(out.to_host(), g["multi_axpy5"]) <= KTOL
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 8), (4, 6, 5), (1, 1, 1), (2, 3, 1), (17, 9, 11)])
+def test_hpcg_generator_bit_exact(ctx, oracle, shape):
+    nx, ny, nz = shape
+    N = nx * ny * nz
+    for row0, row1 in [(0, N), (N // 3, N - N // 4), (0, 0)]:
+        ref = oracle.gen_hpcg(nx, ny, nz, row0, row1)
+        d = ctx.gen_hpcg(nx, ny, nz, row0, row1)
+        rp, col, val = d.download()
+        assert d.n_rows == row1 - row0 and d.n_cols == N
+        assert np.array_equal(rp, ref.row_ptr)
+        assert np.array_equal(col, ref.col)
+        assert np.array_equal(val, ref.val)
+        d.free()
+
+
+@pytest.mark.parametrize("L,shift", [(3, 0.0), (8, 9.0), (13, 0.0)])
+def test_anderson_generator_bit_exact(ctx, oracle, L, shift):
+    N = L ** 3
+    for row0, row1 in [(0, N), (N // 5, N // 2)]:
+        ref = oracle.gen_anderson(L, shift=shift, row0=row0, row1=row1)
+        d = ctx.gen_anderson(L, shift=shift, row0=row0, row1=row1)
+        rp, col, val = d.download()
+        assert np.array_equal(rp, ref.row_ptr)
+        assert np.array_equal(col, ref.col)
+        assert np.array_equal(val, ref.val)
+        d.free()
+
+
+@pytest.mark.parametrize("name", GOLDEN_MATS)
+def test_split_strict_bit_exact(ctx, name):
+    """Device split_LU/peel_diag (LU_factors.hpp:122-309, :827-869) vs the
+    reference's outputs."""
+    g = load_golden(name)
+    dA = ctx.matrix(crs_of(g, "A"))
+    dLs, dUs, D, Dinv = ctx.split_strict(dA)
+    for M, k in ((dLs, "Ls"), (dUs, "Us")):
+        rp, col, val = M.download()
+        assert np.array_equal(rp, g[k + "_rp"])
+        assert np.array_equal(col, g[k + "_col"])
+        assert np.array_equal(val, g[k + "_val"])
+    assert np.array_equal(D.to_host(), g["A_D"])
+    assert np.array_equal(Dinv.to_host(), g["A_D_inv"])
+
+
+def test_split_strict_diag_errors(ctx):
+    from basic_iterative_solvers_amd import BisError
+    A = CRS(3, [0, 2, 3, 5], [0, 1, 0, 1, 2], [1.0, 2.0, 3.0, 4.0, 5.0])  # row 1 has no diagonal
+    with pytest.raises(BisError, match="No diagonal to extract at row index 1"):
+        ctx.split_strict(ctx.matrix(A))
+    A = CRS(2, [0, 1, 2], [0, 1], [1.0, 0.0])
+    with pytest.raises(BisError, match="Zero detected on diagonal at row index 1"):
+        ctx.split_strict(ctx.matrix(A))
+
+
+def test_spmv_ragged_unsorted_and_empty_rows(ctx, oracle):
+    rng = np.random.default_rng(7)
+    n = 5000
+    lens = rng.integers(0, 40, n)
+    lens[::97] = 0          # empty rows
+    lens[1234] = 3000       # one long row inside the LDS budget
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    col = rng.integers(0, n, rp[-1]).astype(np.int32)  # unsorted, duplicates allowed
+    val = rng.uniform(-1, 1, rp[-1])
+    A = CRS(n, rp, col, val)
+    x = rng.uniform(-1, 1, n)
+    y = dev_spmv(ctx, A, x)
+    yo = oracle.spmv(A, x)
+    scale = np.abs(A.to_scipy()).dot(np.abs(x)).max()
+    assert np.max(np.abs(y - yo)) <= KTOL * scale
+
+
+def test_spmv_very_long_rows_fallback(ctx, oracle):
+    rng = np.random.default_rng(8)
+    n = 64
+    lens = np.full(n, 5)
+    lens[3] = 20000  # exceeds the LDS budget -> wave-per-row kernel
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    col = rng.integers(0, n, rp[-1]).astype(np.int32)
+    val = rng.uniform(-1, 1, rp[-1])
+    A = CRS(n, rp, col, val)
+    x = rng.uniform(-1, 1, n)
+    y = dev_spmv(ctx, A, x)
+    yo = oracle.spmv(A, x)
+    scale = np.abs(A.to_scipy()).dot(np.abs(x)).max()
+    assert np.max(np.abs(y - yo)) <= KTOL * scale
+
+
+def test_spmv_degenerate_shapes(ctx, oracle):
+    # empty matrix, all-empty rows, single entry
+    A = CRS(0, [0], [], [])
+    dA = ctx.matrix(A)
+    ctx.spmv(dA, ctx.alloc(1), ctx.alloc(1))
+    A = CRS(4, [0, 0, 0, 0, 0], [], [])
+    assert np.array_equal(dev_spmv(ctx, A, np.ones(4)), np.zeros(4))
+    A = CRS(1, [0, 1], [0], [2.5])
+    assert np.array_equal(dev_spmv(ctx, A, np.array([4.0])), np.array([10.0]))
+
+
+def test_reference_unit_vectors(ctx):
+    """tests/test_kernels.cpp:30-64, :72-88, :99-115 of the reference."""
+    A = CRS(3, [0, 3, 6, 9], [0, 1, 2] * 3, np.arange(1.0, 10.0))
+    assert np.allclose(dev_spmv(ctx, A, np.array([1.0, 2.0, 3.0])), [14, 32, 50], atol=1e-9)
+    D = ctx.upload([2.0, 3.0, 4.0])
+    Ls = ctx.matrix(CRS(3, [0, 0, 1, 3], [0, 0, 1], [1.0, -2.0, 1.0]))
+    x = ctx.alloc(3)
+    ctx.sptrsv(Ls, x, D, ctx.upload([2.0, 7.0, 12.0]))
+    assert np.allclose(x.to_host(), [1, 2, 3], atol=1e-9)
+    Us = ctx.matrix(CRS(3, [0, 2, 3, 3], [1, 2, 2], [1.0, -2.0, 1.0]))
+    ctx.bsptrsv(Us, x, D, ctx.upload([-2.0, 9.0, 12.0]))
+    assert np.allclose(x.to_host(), [1, 2, 3], atol=1e-9)
+    assert ctx.euclidean_vec_norm(ctx.alloc(0), 0) == 0.0  # empty vector
+
+
+@pytest.mark.parametrize("kind,size", [("hpcg", 32), ("anderson", 40)])
+def test_medium_size_vs_oracle(ctx, oracle, kind, size):
+    """Sizes the oracle finishes in seconds: SpMV, triangular solves (natural
+    order arithmetic -> bit-exact against the fma oracle) and BLAS-1."""
+    A = oracle.gen_hpcg(size) if kind == "hpcg" else oracle.gen_anderson(size, shift=9.0)
+    n = A.n_rows
+    rng = np.random.default_rng(12345)
+    x, b = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    dA = ctx.gen_hpcg(size) if kind == "hpcg" else ctx.gen_anderson(size, shift=9.0)
+    dx, db, out = ctx.upload(x), ctx.upload(b), ctx.alloc(n)
+    ctx.spmv(dA, dx, out)
+    yo = oracle.spmv(A, x)
+    assert relerr(out.to_host(), yo) <= KTOL
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    dLs, dUs, dD, dDinv = ctx.split_strict(dA)
+    assert np.array_equal(dD.to_host(), D)
+    ctx.sptrsv(dLs, out, dD, db)
+    assert np.array_equal(out.to_host(), oracle.sptrsv(Ls, D, b))
+    ctx.bsptrsv(dUs, out, dD, db)
+    assert np.array_equal(out.to_host(), oracle.sptrsv(Us, D, b, backward=True))
+    assert abs(ctx.dot(dx, db) - oracle.dot(x, b)) <= KTOL * np.abs(x).dot(np.abs(b))
+    assert abs(ctx.euclidean_vec_norm(dx) - oracle.norm(x)) <= KTOL * oracle.norm(x)
+
+
+_H = load_histories()
+_CG_KEYS = sorted(k for k in _H if k.split("|")[1] == "cg" and k.split("|")[2] in ("none", "j")
+                  and "num_scale" not in k)
+
+
+@pytest.mark.parametrize("key", _CG_KEYS)
+def test_fused_cg_history_vs_reference(ctx, key):
+    """bis_cg_* (fused device schedule) vs the reference's residual tables:
+    max_k |r_k - r_k^ref| <= 1e-10 r_0, same iteration count."""
+    e = _H[key]
+    name, solver, pc, kw = parse_hist_key(key)
+    g = load_golden(name)
+    A = crs_of(g, "A")
+    n = A.n_rows
+    dA = ctx.matrix(A)
+    b, x = ctx.upload(np.full(n, 1.0)), ctx.upload(np.full(n, 0.1))
+    dD = ctx.upload(g["A_D"]) if pc == "j" else None
+    cg = ctx.cg(dA, b, x, dD)
+    r0 = cg.init(1e-14)
+    assert abs(r0 - e["hist"][0]) <= 1e-13 * e["hist"][0]
+    cg.iterate(1000)
+    iters, conv, hist = cg.status()
+    check_history(dict(hist=hist, iters=iters, converged=conv), e, "cg")
+    if e["converged"]:
+        # true residual of the returned x (solver.hpp:153-159)
+        res, tmp = ctx.alloc(n), ctx.alloc(n)
+        ctx.compute_residual(dA, x, b, res, tmp)
+        assert ctx.euclidean_vec_norm(res) <= 1e-9 * e["hist"][0]
+    cg.free()
+
+
+def test_full_size_hpcg256_properties(ctx):
+    """BASELINE metric size (HPCG 256^3, 449,455,096 nnz): size-independent
+    properties -- row sums in closed form, linearity, and the fused CG
+    history staying consistent with the unfused kernels."""
+    n1 = 256
+    dA = ctx.gen_hpcg(n1)
+    N = n1 ** 3
+    assert dA.nnz == (3 * n1 - 2) ** 3
+    ones, y = ctx.alloc(N), ctx.alloc(N)
+    ctx.init_vector(ones, 1.0)
+    ctx.spmv(dA, ones, y)
+    yh = y.to_host().reshape(n1, n1, n1)
+    # A*1 = 26 - (neighbours) = 27 - cx*cy*cz
+    c = np.full(n1, 3.0); c[0] = c[-1] = 2.0
+    expect = 27.0 - c[:, None, None] * c[None, :, None] * c[None, None, :]
+    assert np.array_equal(yh, expect)
+    rng = np.random.default_rng(1)
+    u, v = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N)
+    du, dv, dw = ctx.upload(u), ctx.upload(v), ctx.alloc(N)
+    yu, yv, yw = ctx.alloc(N), ctx.alloc(N), ctx.alloc(N)
+    ctx.sum_vectors(dw, du, dv, -0.75)
+    ctx.spmv(dA, du, yu); ctx.spmv(dA, dv, yv); ctx.spmv(dA, dw, yw)
+    ctx.sum_vectors(yu, yu, yv, -0.75)
+    ctx.subtract_vectors(yu, yu, yw, 1.0)
+    assert ctx.euclidean_vec_norm(yu) <= 1e-13 * 52 * np.sqrt(N)
+    # symmetry: (Au, v) == (u, Av)
+    ctx.spmv(dA, du, yu); ctx.spmv(dA, dv, yv)
+    a, b2 = ctx.dot(yu, dv), ctx.dot(du, yv)
+    assert abs(a - b2) <= 1e-12 * max(abs(a), 1.0) * 10
