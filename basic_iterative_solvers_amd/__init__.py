@@ -296,3 +296,104 @@ class CG:
         if self.h:
             self.ctx.lib.bis_cg_destroy(self.ctx.h, self.h)
             self.h = C.c_void_p()
+
+
+# ---- multi-GPU (1-D row partition) -------------------------------------------
+class CommOps(C.Structure):
+    _fields_ = [("user", C.c_void_p),
+                ("allreduce_sum", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)),
+                ("exchange", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                                         C.c_int))]
+
+
+def halo_plan(n_local, row_ptr, col_global, n_ranks, rank, row_starts):
+    """Host-only planning (bis_halo_plan): returns (halo_cols, recv_counts, interior)."""
+    lib = load_library()
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    col = np.ascontiguousarray(col_global, dtype=np.int32)
+    rs = np.ascontiguousarray(row_starts, dtype=np.int64)
+    n_halo = C.c_int64()
+    recv = np.zeros(n_ranks, dtype=np.int64)
+    interior = np.zeros(2, dtype=np.int64)
+    st = lib.bis_halo_plan(_i64(n_local), rp.ctypes, col.ctypes, C.c_int(n_ranks), C.c_int(rank),
+                           rs.ctypes, C.byref(n_halo), None, _i64(0), recv.ctypes, interior.ctypes)
+    if st != 0:
+        raise BisError(f"bis_halo_plan failed: {st}")
+    halo = np.zeros(n_halo.value, dtype=np.int32)
+    st = lib.bis_halo_plan(_i64(n_local), rp.ctypes, col.ctypes, C.c_int(n_ranks), C.c_int(rank),
+                           rs.ctypes, C.byref(n_halo), halo.ctypes, _i64(halo.size), recv.ctypes,
+                           interior.ctypes)
+    if st != 0:
+        raise BisError(f"bis_halo_plan failed: {st}")
+    return halo, recv, interior
+
+
+class Dist:
+    """bis_dist: the row-partitioned operator of one rank."""
+
+    def __init__(self, ctx, A_local, rank, n_ranks, row_starts):
+        self.ctx, self.rank, self.n_ranks = ctx, rank, n_ranks
+        self.row_starts = np.ascontiguousarray(row_starts, dtype=np.int64)
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.bis_dist_create(ctx.h, A_local.h, C.c_int(rank), C.c_int(n_ranks),
+                                          self.row_starts.ctypes, C.byref(self.h)))
+        A_local.h = C.c_void_p()  # consumed
+        nl, ne = C.c_int64(), C.c_int64()
+        ctx.lib.bis_dist_vec_len(self.h, C.byref(nl), C.byref(ne))
+        self.n_local, self.n_ext = nl.value, ne.value
+        self._keep = None
+
+    def halo_info(self):
+        n_halo = C.c_int64()
+        recv = np.zeros(self.n_ranks, dtype=np.int64)
+        self.ctx.lib.bis_dist_halo_info(self.h, C.byref(n_halo), None, _i64(0), recv.ctypes)
+        halo = np.zeros(n_halo.value, dtype=np.int32)
+        self.ctx.lib.bis_dist_halo_info(self.h, C.byref(n_halo), halo.ctypes, _i64(halo.size),
+                                        recv.ctypes)
+        return halo, recv
+
+    def set_send_lists(self, send_counts, send_cols):
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        cols = np.ascontiguousarray(send_cols, dtype=np.int32)
+        self.ctx.check(self.ctx.lib.bis_dist_set_send_lists(self.ctx.h, self.h, sc.ctypes, cols.ctypes))
+
+    def set_comm(self, ops):
+        self._keep = ops  # keep the callbacks alive
+        self.ctx.check(self.ctx.lib.bis_dist_set_comm(self.ctx.h, self.h, C.byref(ops)))
+
+    def use_rccl(self, unique_id_bytes):
+        buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
+        self.ctx.check(self.ctx.lib.bis_dist_use_rccl(self.ctx.h, self.h, buf))
+
+    def spmv(self, x_ext, y):
+        self.ctx.check(self.ctx.lib.bis_dist_spmv(self.ctx.h, self.h, C.c_void_p(x_ext.ptr),
+                                                  C.c_void_p(y.ptr)))
+
+    def dot(self, a, b):
+        out = C.c_double()
+        dev = self.ctx.alloc(1)
+        self.ctx.check(self.ctx.lib.bis_dist_dot(self.ctx.h, self.h, C.c_void_p(a.ptr),
+                                                 C.c_void_p(b.ptr), C.c_void_p(dev.ptr), C.byref(out)))
+        dev.free()
+        return out.value
+
+    def cg(self, b, x, A_D=None):
+        cg = CG.__new__(CG)
+        cg.ctx = self.ctx
+        cg.h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.bis_dist_cg_create(
+            self.ctx.h, self.h, C.c_void_p(A_D.ptr) if A_D else C.c_void_p(), C.c_void_p(b.ptr),
+            C.c_void_p(x.ptr), C.byref(cg.h)))
+        return cg
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.bis_dist_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+def rccl_unique_id(ctx):
+    buf = C.create_string_buffer(128)
+    ctx.check(ctx.lib.bis_rccl_unique_id(ctx.h, buf))
+    return bytes(buf.raw)

@@ -21,10 +21,20 @@
 // is exactly the state at the reference's stopping iteration.
 #include "bis_internal.hpp"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
+struct bis_dist;
+bis_status bis_dist_spmv_launch(bis_ctx *ctx, bis_dist *d, double *x_ext, double *y, const double *w,
+                                int *n_partials);
+int bis_dist_total_blocks(const bis_dist *d);
+int64_t bis_dist_n_local(const bis_dist *d);
+int64_t bis_dist_n_ext(const bis_dist *d);
+bis_status bis_dist_allreduce(bis_ctx *ctx, bis_dist *d, double *buf_dev, int count);
+
 struct bis_cg {
+    bis_dist *dist = nullptr;    // non-null: row-partitioned operator
     const bis_mat *A = nullptr;
     const double *A_D = nullptr; // nullptr: no preconditioner
     const double *b = nullptr;
@@ -40,7 +50,7 @@ struct bis_cg {
 
 namespace {
 
-enum { S_RZ = 0, S_PAP, S_RZ_NEW, S_RR, S_ALPHA, S_BETA, S_STOP, S_COUNT = 8 };
+enum { S_RZ = 0, S_PAP, S_RZ_NEW, S_RR, S_ALPHA, S_BETA, S_STOP, S_COUNT = 8 }; // S_RZ_NEW,S_RR adjacent
 constexpr int kT = 256;
 constexpr int kMaxIters = 1 << 20;
 
@@ -117,18 +127,27 @@ __global__ __launch_bounds__(1024) void cg_finish_pap_kernel(const double *parti
     if (threadIdx.x == 0) sc[S_PAP] = s;
 }
 
-// reduce (r,z), (r,r); record the residual norm; beta; stop test
+// reduce (r,z), (r,r); record the residual norm; beta; stop test.
+// REDUCE: sum the per-block partials into sc[S_RZ_NEW], sc[S_RR];
+// BOOK: the scalar bookkeeping.  Single GPU runs both in one launch; the
+// distributed schedule puts the all-reduce of the two sums in between.
+template <bool REDUCE, bool BOOK>
 __global__ __launch_bounds__(256) void cg_scalars_kernel(const double *partials, int n_partials,
                                                          size_t stride, double *sc, int *flags,
                                                          double *hist, int hist_cap) {
     __shared__ double lds[4];
     if (flags[1]) return;
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = threadIdx.x; i < n_partials; i += 256) { a0 += partials[i]; a1 += partials[stride + i]; }
-    const double rz_new = block_sum<256>(a0, lds);
-    __syncthreads();
-    const double rr = block_sum<256>(a1, lds);
-    if (threadIdx.x == 0) {
+    double rz_new = 0.0, rr = 0.0;
+    if (REDUCE) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int i = threadIdx.x; i < n_partials; i += 256) { a0 += partials[i]; a1 += partials[stride + i]; }
+        rz_new = block_sum<256>(a0, lds);
+        __syncthreads();
+        rr = block_sum<256>(a1, lds);
+        if (!BOOK && threadIdx.x == 0) { sc[S_RZ_NEW] = rz_new; sc[S_RR] = rr; }
+    }
+    if (BOOK && threadIdx.x == 0) {
+        if (!REDUCE) { rz_new = sc[S_RZ_NEW]; rr = sc[S_RR]; }
         const double rz_old = sc[S_RZ];
         sc[S_BETA] = rz_new / rz_old;          // cg.hpp:47
         sc[S_RZ] = rz_new;
@@ -178,19 +197,18 @@ inline int grid_for(int64_t n) {
 
 extern "C" {
 
-bis_status bis_cg_create(bis_ctx *ctx, const bis_mat *A, const double *A_D, const double *b,
-                         double *x, bis_cg **out) {
-    BIS_CTX_OK(ctx);
-    BIS_REQUIRE(ctx, A && b && x && out, "bis_cg_create: bad arguments");
-    BIS_REQUIRE(ctx, A->n_rows == A->n_cols, "bis_cg_create: square matrix required");
+static bis_status cg_create_common(bis_ctx *ctx, bis_dist *dist, const bis_mat *A, const double *A_D,
+                                   const double *b, double *x, bis_cg **out) {
     bis_cg *cg = new bis_cg;
+    cg->dist = dist;
     cg->A = A;
     cg->A_D = A_D;
     cg->b = b;
     cg->x = x;
-    cg->n = A->n_rows;
+    cg->n = dist ? bis_dist_n_local(dist) : A->n_rows;
+    const int64_t n_ext = dist ? bis_dist_n_ext(dist) : cg->n; // p is the SpMV input: needs the halo tail
     cg->hist_cap = 4096;
-    bis_status st = bis_vec_alloc(ctx, cg->n, &cg->p);
+    bis_status st = bis_vec_alloc(ctx, n_ext, &cg->p);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->n, &cg->r);
     if (st == BIS_OK && A_D) st = bis_vec_alloc(ctx, cg->n, &cg->z);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->n, &cg->tmp);
@@ -201,6 +219,21 @@ bis_status bis_cg_create(bis_ctx *ctx, const bis_mat *A, const double *A_D, cons
     if (!A_D) cg->z = cg->r; // z aliases r without a preconditioner
     *out = cg;
     return BIS_OK;
+}
+
+bis_status bis_cg_create(bis_ctx *ctx, const bis_mat *A, const double *A_D, const double *b,
+                         double *x, bis_cg **out) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A && b && x && out, "bis_cg_create: bad arguments");
+    BIS_REQUIRE(ctx, A->n_rows == A->n_cols, "bis_cg_create: square matrix required");
+    return cg_create_common(ctx, nullptr, A, A_D, b, x, out);
+}
+
+bis_status bis_dist_cg_create(bis_ctx *ctx, bis_dist *d, const double *A_D, const double *b,
+                              double *x, bis_cg **out) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d && b && x && out, "bis_dist_cg_create: bad arguments");
+    return cg_create_common(ctx, d, nullptr, A_D, b, x, out);
 }
 
 bis_status bis_cg_destroy(bis_ctx *ctx, bis_cg *cg) {
@@ -223,12 +256,24 @@ bis_status bis_cg_init(bis_ctx *ctx, bis_cg *cg, double tol, double *r0_norm_hos
     BIS_REQUIRE(ctx, cg, "bis_cg_init: null handle");
     const int64_t n = cg->n;
     // init_residual, cg.hpp:100-118
-    bis_status st = bis_compute_residual(ctx, cg->A, cg->x, cg->b, cg->r, cg->tmp);
+    bis_status st;
+    double rz = 0.0, rr = 0.0;
+    if (cg->dist) {
+        st = bis_copy_vector(ctx, cg->p, cg->x, n); // SpMV input needs the halo tail: stage x in p
+        if (st == BIS_OK) st = bis_dist_spmv_launch(ctx, cg->dist, cg->p, cg->tmp, nullptr, nullptr);
+        if (st == BIS_OK) st = bis_subtract_vectors(ctx, cg->r, cg->b, cg->tmp, n, 1.0);
+    } else {
+        st = bis_compute_residual(ctx, cg->A, cg->x, cg->b, cg->r, cg->tmp);
+    }
     if (st == BIS_OK && cg->A_D) st = bis_elemwise_div_vectors(ctx, cg->z, cg->r, cg->A_D, n, 1.0);
     if (st == BIS_OK) st = bis_copy_vector(ctx, cg->p, cg->z, n);
-    double rz = 0.0, rr = 0.0;
-    if (st == BIS_OK) st = bis_dot(ctx, cg->r, cg->z, n, &rz);
-    if (st == BIS_OK) st = bis_dot(ctx, cg->r, cg->r, n, &rr);
+    if (cg->dist) {
+        if (st == BIS_OK) st = bis_dist_dot(ctx, cg->dist, cg->r, cg->z, ctx->scalars_dev + 8, &rz);
+        if (st == BIS_OK) st = bis_dist_dot(ctx, cg->dist, cg->r, cg->r, ctx->scalars_dev + 8, &rr);
+    } else {
+        if (st == BIS_OK) st = bis_dot(ctx, cg->r, cg->z, n, &rz);
+        if (st == BIS_OK) st = bis_dot(ctx, cg->r, cg->r, n, &rr);
+    }
     if (st != BIS_OK) return st;
     const double norm0 = sqrt(rr);
     double sc[S_COUNT] = {0};
@@ -252,14 +297,20 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
     const int64_t n = cg->n;
     if (n == 0) return BIS_OK;
     const int g = grid_for(n);
-    bis_status st = bis_ensure_partials(ctx, (size_t)2 * kMaxReduceBlocks);
+    const size_t nblk = cg->dist ? (size_t)bis_dist_total_blocks(cg->dist) : (size_t)cg->A->n_blocks;
+    bis_status st = bis_ensure_partials(ctx, std::max((size_t)2 * kMaxReduceBlocks, nblk));
     if (st != BIS_OK) return st;
     for (int it = 0; it < n_iters; ++it) {
         int n_part = 0;
-        st = bis_spmv_launch(ctx, cg->A, cg->p, cg->tmp, cg->p, &n_part);
+        if (cg->dist) st = bis_dist_spmv_launch(ctx, cg->dist, cg->p, cg->tmp, cg->p, &n_part);
+        else st = bis_spmv_launch(ctx, cg->A, cg->p, cg->tmp, cg->p, &n_part);
         if (st != BIS_OK) return st;
         hipLaunchKernelGGL(cg_finish_pap_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials,
                            n_part, cg->sc, cg->flags);
+        if (cg->dist) {
+            st = bis_dist_allreduce(ctx, cg->dist, cg->sc + S_PAP, 1);
+            if (st != BIS_OK) return st;
+        }
         if (cg->A_D)
             hipLaunchKernelGGL(cg_update_kernel<true>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc,
                                cg->flags, cg->p, cg->tmp, cg->A_D, cg->x, cg->r, cg->z, ctx->partials,
@@ -268,8 +319,20 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
             hipLaunchKernelGGL(cg_update_kernel<false>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc,
                                cg->flags, cg->p, cg->tmp, cg->A_D, cg->x, cg->r, cg->z, ctx->partials,
                                (size_t)kMaxReduceBlocks);
-        hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, g,
-                           (size_t)kMaxReduceBlocks, cg->sc, cg->flags, cg->hist, cg->hist_cap);
+        if (cg->dist) {
+            hipLaunchKernelGGL((cg_scalars_kernel<true, false>), dim3(1), dim3(256), 0, ctx->stream,
+                               ctx->partials, g, (size_t)kMaxReduceBlocks, cg->sc, cg->flags, cg->hist,
+                               cg->hist_cap);
+            st = bis_dist_allreduce(ctx, cg->dist, cg->sc + S_RZ_NEW, 2); // {(r,z),(r,r)} batched
+            if (st != BIS_OK) return st;
+            hipLaunchKernelGGL((cg_scalars_kernel<false, true>), dim3(1), dim3(64), 0, ctx->stream,
+                               ctx->partials, g, (size_t)kMaxReduceBlocks, cg->sc, cg->flags, cg->hist,
+                               cg->hist_cap);
+        } else {
+            hipLaunchKernelGGL((cg_scalars_kernel<true, true>), dim3(1), dim3(256), 0, ctx->stream,
+                               ctx->partials, g, (size_t)kMaxReduceBlocks, cg->sc, cg->flags, cg->hist,
+                               cg->hist_cap);
+        }
         hipLaunchKernelGGL(cg_p_update_kernel, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags,
                            cg->z, cg->p);
     }

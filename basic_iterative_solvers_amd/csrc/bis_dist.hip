@@ -1,0 +1,436 @@
+// bis_dist.hip -- 1-D row-block partition of the hot path across GPUs
+// (SURVEY.md section 8e).  The reference is single-process OpenMP; this layer
+// is new.  One process per GPU; rank g owns a contiguous global row range.
+//
+//   SpMV   : pack boundary x entries -> halo exchange (second stream, RCCL
+//            ncclSend/ncclRecv pairs over xGMI, or the launcher's transport)
+//            overlapped with the SpMV of the interior rows (no remote column)
+//            -> SpMV of the boundary rows on [x_local | halo].
+//   dot    : local two-stage reduction -> all-reduce of 1-2 doubles.
+//
+// Local column numbering: owned columns -> [0, n_local); the k-th distinct
+// remote column (sorted by global index, hence grouped by owner) ->
+// n_local + k, so the exchange receives straight into the tail of the SpMV
+// input vector.
+#include "bis_internal.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+
+struct bis_dist {
+    int rank = 0, n_ranks = 1;
+    int64_t row0 = 0, row1 = 0, n_local = 0, n_halo = 0;
+    std::vector<int64_t> row_starts;
+    bis_mat *A = nullptr;                 // local rows, renumbered columns (owned)
+    bis_mat *lo = nullptr, *mid = nullptr, *hi = nullptr; // row views
+    int64_t mid_a = 0, mid_b = 0;
+    std::vector<int32_t> halo_cols;       // global indices, sorted
+    std::vector<int64_t> recv_counts, send_counts;
+    int64_t n_send = 0;
+    int32_t *send_idx = nullptr;          // device: local indices to pack
+    double *sendbuf = nullptr;            // device
+    bis_comm_ops ops{};
+    bool have_ops = false;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+    // RCCL backend state
+    void *rccl_lib = nullptr;
+    ncclComm_t comm = nullptr;
+    struct {
+        ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+        ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+        ncclResult_t (*CommDestroy)(ncclComm_t);
+        ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+        ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+        ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+        ncclResult_t (*GroupStart)();
+        ncclResult_t (*GroupEnd)();
+        const char *(*GetErrorString)(ncclResult_t);
+    } nccl{};
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void renumber_cols_kernel(int32_t *col, int64_t nnz, int64_t row0,
+                                                            int64_t row1, const int32_t *halo,
+                                                            int64_t n_halo) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t n_local = row1 - row0;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += stride) {
+        const int64_t c = col[k];
+        if (c >= row0 && c < row1) {
+            col[k] = (int32_t)(c - row0);
+        } else {
+            int64_t lo = 0, hi = n_halo;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (halo[mid] < c) lo = mid + 1; else hi = mid;
+            }
+            col[k] = (int32_t)(n_local + lo);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const double *x, const int32_t *idx, int64_t n,
+                                                   double *out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = x[idx[i]];
+}
+
+void *load_rccl() {
+    // prefer a copy that is already mapped (torch ships its own librccl.so);
+    // never mix two RCCL instances in one process
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return h;
+}
+
+template <typename F>
+bool sym(void *lib, const char *name, F &out) {
+    out = reinterpret_cast<F>(dlsym(lib, name));
+    return out != nullptr;
+}
+
+bool bind_rccl(bis_dist *d) {
+    if (d->rccl_lib) return true;
+    void *h = load_rccl();
+    if (!h) return false;
+    bool ok = sym(h, "ncclGetUniqueId", d->nccl.GetUniqueId) &&
+              sym(h, "ncclCommInitRank", d->nccl.CommInitRank) &&
+              sym(h, "ncclCommDestroy", d->nccl.CommDestroy) &&
+              sym(h, "ncclAllReduce", d->nccl.AllReduce) && sym(h, "ncclSend", d->nccl.Send) &&
+              sym(h, "ncclRecv", d->nccl.Recv) && sym(h, "ncclGroupStart", d->nccl.GroupStart) &&
+              sym(h, "ncclGroupEnd", d->nccl.GroupEnd) &&
+              sym(h, "ncclGetErrorString", d->nccl.GetErrorString);
+    if (ok) d->rccl_lib = h;
+    return ok;
+}
+
+int rccl_allreduce(void *user, void *stream, double *buf, int count) {
+    bis_dist *d = (bis_dist *)user;
+    return d->nccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, d->comm,
+                             (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+}
+
+int rccl_exchange(void *user, void *stream, const double *sendbuf, const int64_t *send_counts,
+                  double *recvbuf, const int64_t *recv_counts, int n_ranks) {
+    bis_dist *d = (bis_dist *)user;
+    hipStream_t s = (hipStream_t)stream;
+    bool ok = d->nccl.GroupStart() == ncclSuccess;
+    int64_t so = 0, ro = 0;
+    for (int p = 0; p < n_ranks && ok; ++p) {
+        if (send_counts[p] > 0)
+            ok = ok && d->nccl.Send(sendbuf + so, (size_t)send_counts[p], ncclDouble, p, d->comm, s) == ncclSuccess;
+        if (recv_counts[p] > 0)
+            ok = ok && d->nccl.Recv(recvbuf + ro, (size_t)recv_counts[p], ncclDouble, p, d->comm, s) == ncclSuccess;
+        so += send_counts[p];
+        ro += recv_counts[p];
+    }
+    ok = (d->nccl.GroupEnd() == ncclSuccess) && ok;
+    return ok ? 0 : 1;
+}
+
+} // namespace
+
+extern "C" {
+
+bis_status bis_halo_plan(int64_t n_local, const int64_t *row_ptr, const int32_t *col, int n_ranks,
+                         int rank, const int64_t *row_starts, int64_t *n_halo, int32_t *halo_cols,
+                         int64_t halo_cap, int64_t *recv_counts, int64_t *interior) {
+    if (n_local < 0 || !row_ptr || n_ranks < 1 || rank < 0 || rank >= n_ranks || !row_starts || !n_halo)
+        return BIS_ERR_INVALID;
+    const int64_t row0 = row_starts[rank], row1 = row_starts[rank + 1];
+    if (row1 - row0 != n_local) return BIS_ERR_INVALID;
+    std::vector<int32_t> remote;
+    int64_t best_a = 0, best_b = 0, run_a = 0;
+    for (int64_t r = 0; r < n_local; ++r) {
+        bool has_remote = false;
+        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+            const int64_t c = col[k];
+            if (c < row0 || c >= row1) { remote.push_back((int32_t)c); has_remote = true; }
+        }
+        if (has_remote) {
+            if (r - run_a > best_b - best_a) { best_a = run_a; best_b = r; }
+            run_a = r + 1;
+        }
+    }
+    if (n_local - run_a > best_b - best_a) { best_a = run_a; best_b = n_local; }
+    std::sort(remote.begin(), remote.end());
+    remote.erase(std::unique(remote.begin(), remote.end()), remote.end());
+    *n_halo = (int64_t)remote.size();
+    if (recv_counts) {
+        for (int p = 0; p < n_ranks; ++p) recv_counts[p] = 0;
+        int p = 0;
+        for (int32_t c : remote) {
+            while (p < n_ranks - 1 && c >= row_starts[p + 1]) ++p;
+            if (c < row_starts[p] || c >= row_starts[p + 1]) return BIS_ERR_INVALID; // column outside the global range
+            recv_counts[p]++;
+        }
+    }
+    if (interior) { interior[0] = best_a; interior[1] = best_b; }
+    if (halo_cols) {
+        if (halo_cap < (int64_t)remote.size()) return BIS_ERR_INVALID;
+        std::copy(remote.begin(), remote.end(), halo_cols);
+    }
+    return BIS_OK;
+}
+
+bis_status bis_dist_create(bis_ctx *ctx, bis_mat *A, int rank, int n_ranks, const int64_t *row_starts,
+                           bis_dist **out) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A && out && n_ranks >= 1 && rank >= 0 && rank < n_ranks && row_starts,
+                "bis_dist_create: bad arguments");
+    BIS_REQUIRE(ctx, !A->view, "bis_dist_create: A_local must own its arrays");
+    const int64_t row0 = row_starts[rank], row1 = row_starts[rank + 1];
+    BIS_REQUIRE(ctx, row1 - row0 == A->n_rows, "bis_dist_create: row range does not match A_local");
+    BIS_REQUIRE(ctx, row_starts[n_ranks] == A->n_cols, "bis_dist_create: A_local.n_cols must be the global size");
+    bis_dist *d = new bis_dist;
+    d->rank = rank;
+    d->n_ranks = n_ranks;
+    d->row0 = row0;
+    d->row1 = row1;
+    d->n_local = A->n_rows;
+    d->row_starts.assign(row_starts, row_starts + n_ranks + 1);
+    d->recv_counts.assign(n_ranks, 0);
+    d->send_counts.assign(n_ranks, 0);
+    // plan on the host from the downloaded structure
+    std::vector<int64_t> rp(A->n_rows + 1);
+    std::vector<int32_t> col((size_t)std::max<int64_t>(A->nnz, 1));
+    bis_status st = bis_mat_download(ctx, A, rp.data(), col.data(), nullptr);
+    int64_t interior[2] = {0, 0};
+    if (st == BIS_OK) {
+        st = bis_halo_plan(A->n_rows, rp.data(), col.data(), n_ranks, rank, row_starts, &d->n_halo,
+                           nullptr, 0, d->recv_counts.data(), interior);
+        if (st == BIS_OK) {
+            d->halo_cols.resize((size_t)d->n_halo);
+            st = bis_halo_plan(A->n_rows, rp.data(), col.data(), n_ranks, rank, row_starts, &d->n_halo,
+                               d->halo_cols.data(), d->n_halo, d->recv_counts.data(), interior);
+        }
+        if (st != BIS_OK) ctx->err = "bis_dist_create: halo planning failed (column outside the global range?)";
+    }
+    if (st != BIS_OK) { delete d; return st; }
+    // renumber the columns on the device
+    int32_t *halo_dev = nullptr;
+    hipError_t e = hipMalloc(&halo_dev, sizeof(int32_t) * (size_t)std::max<int64_t>(d->n_halo, 1));
+    if (e == hipSuccess && d->n_halo)
+        e = hipMemcpyAsync(halo_dev, d->halo_cols.data(), sizeof(int32_t) * (size_t)d->n_halo,
+                           hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && A->nnz) {
+        const int grid = (int)std::min<int64_t>((A->nnz + 255) / 256, 8192);
+        hipLaunchKernelGGL(renumber_cols_kernel, dim3(grid), dim3(256), 0, ctx->stream, A->col, A->nnz,
+                           row0, row1, halo_dev, d->n_halo);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(halo_dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_packed, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        ctx->err = std::string("bis_dist_create: ") + hipGetErrorString(e);
+        delete d;
+        return BIS_ERR_HIP;
+    }
+    A->n_cols = d->n_local + d->n_halo;
+    d->A = A;
+    d->mid_a = interior[0];
+    d->mid_b = interior[1];
+    st = bis_mat_row_view(ctx, A, 0, d->mid_a, &d->lo);
+    if (st == BIS_OK) st = bis_mat_row_view(ctx, A, d->mid_a, d->mid_b, &d->mid);
+    if (st == BIS_OK) st = bis_mat_row_view(ctx, A, d->mid_b, A->n_rows, &d->hi);
+    if (st != BIS_OK) { bis_dist_destroy(ctx, d); return st; }
+    *out = d;
+    return BIS_OK;
+}
+
+bis_status bis_dist_destroy(bis_ctx *ctx, bis_dist *d) {
+    BIS_CTX_OK(ctx);
+    if (!d) return BIS_OK;
+    hipStreamSynchronize(ctx->stream);
+    if (d->comm_stream) hipStreamSynchronize(d->comm_stream);
+    if (d->comm && d->nccl.CommDestroy) d->nccl.CommDestroy(d->comm);
+    bis_mat_destroy(ctx, d->lo);
+    bis_mat_destroy(ctx, d->mid);
+    bis_mat_destroy(ctx, d->hi);
+    bis_mat_destroy(ctx, d->A);
+    hipFree(d->send_idx);
+    hipFree(d->sendbuf);
+    if (d->ev_packed) hipEventDestroy(d->ev_packed);
+    if (d->ev_halo) hipEventDestroy(d->ev_halo);
+    if (d->comm_stream) hipStreamDestroy(d->comm_stream);
+    delete d;
+    return BIS_OK;
+}
+
+bis_status bis_dist_vec_len(const bis_dist *d, int64_t *n_local, int64_t *n_ext) {
+    if (!d) return BIS_ERR_INVALID;
+    if (n_local) *n_local = d->n_local;
+    if (n_ext) *n_ext = d->n_local + d->n_halo;
+    return BIS_OK;
+}
+
+bis_status bis_dist_halo_info(const bis_dist *d, int64_t *n_halo, int32_t *halo_cols, int64_t halo_cap,
+                              int64_t *recv_counts) {
+    if (!d) return BIS_ERR_INVALID;
+    if (n_halo) *n_halo = d->n_halo;
+    if (halo_cols) {
+        if (halo_cap < d->n_halo) return BIS_ERR_INVALID;
+        std::copy(d->halo_cols.begin(), d->halo_cols.end(), halo_cols);
+    }
+    if (recv_counts) std::copy(d->recv_counts.begin(), d->recv_counts.end(), recv_counts);
+    return BIS_OK;
+}
+
+bis_status bis_dist_set_send_lists(bis_ctx *ctx, bis_dist *d, const int64_t *send_counts,
+                                   const int32_t *send_cols_global) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d && send_counts, "bis_dist_set_send_lists: bad arguments");
+    int64_t total = 0;
+    for (int p = 0; p < d->n_ranks; ++p) {
+        BIS_REQUIRE(ctx, send_counts[p] >= 0, "bis_dist_set_send_lists: negative count");
+        d->send_counts[p] = send_counts[p];
+        total += send_counts[p];
+    }
+    BIS_REQUIRE(ctx, total == 0 || send_cols_global, "bis_dist_set_send_lists: null list");
+    std::vector<int32_t> idx((size_t)std::max<int64_t>(total, 1));
+    for (int64_t i = 0; i < total; ++i) {
+        const int64_t c = send_cols_global[i];
+        BIS_REQUIRE(ctx, c >= d->row0 && c < d->row1,
+                    "bis_dist_set_send_lists: requested column is not owned by this rank");
+        idx[i] = (int32_t)(c - d->row0);
+    }
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d->send_idx);
+    hipFree(d->sendbuf);
+    d->send_idx = nullptr;
+    d->sendbuf = nullptr;
+    BIS_HIP_CHECK(ctx, hipMalloc(&d->send_idx, sizeof(int32_t) * idx.size()));
+    BIS_HIP_CHECK(ctx, hipMalloc(&d->sendbuf, sizeof(double) * idx.size()));
+    BIS_HIP_CHECK(ctx, hipMemcpy(d->send_idx, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice));
+    d->n_send = total;
+    return BIS_OK;
+}
+
+bis_status bis_dist_set_comm(bis_ctx *ctx, bis_dist *d, const bis_comm_ops *ops) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d && ops && ops->allreduce_sum && ops->exchange, "bis_dist_set_comm: bad arguments");
+    d->ops = *ops;
+    d->have_ops = true;
+    return BIS_OK;
+}
+
+bis_status bis_rccl_unique_id(bis_ctx *ctx, void *out128) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, out128, "bis_rccl_unique_id: null output");
+    bis_dist tmp;
+    if (!bind_rccl(&tmp)) { ctx->err = "RCCL library not found (librccl.so.1)"; return BIS_ERR_COMM; }
+    ncclUniqueId id;
+    if (tmp.nccl.GetUniqueId(&id) != ncclSuccess) { ctx->err = "ncclGetUniqueId failed"; return BIS_ERR_COMM; }
+    static_assert(sizeof(id) == 128, "ncclUniqueId size");
+    memcpy(out128, &id, 128);
+    return BIS_OK;
+}
+
+bis_status bis_dist_use_rccl(bis_ctx *ctx, bis_dist *d, const void *unique_id128) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d && unique_id128, "bis_dist_use_rccl: bad arguments");
+    if (!bind_rccl(d)) { ctx->err = "RCCL library not found (librccl.so.1)"; return BIS_ERR_COMM; }
+    ncclUniqueId id;
+    memcpy(&id, unique_id128, 128);
+    BIS_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const ncclResult_t r = d->nccl.CommInitRank(&d->comm, d->n_ranks, id, d->rank);
+    if (r != ncclSuccess) {
+        ctx->err = std::string("ncclCommInitRank: ") + d->nccl.GetErrorString(r);
+        return BIS_ERR_COMM;
+    }
+    d->ops.user = d;
+    d->ops.allreduce_sum = rccl_allreduce;
+    d->ops.exchange = rccl_exchange;
+    d->have_ops = true;
+    return BIS_OK;
+}
+
+} // extern "C"
+
+// internal (also used by the distributed CG): SpMV with the halo exchange
+// overlapped; w/partials as in bis_spmv_launch (partials of the three row
+// ranges are laid out back to back, *n_partials = total).
+bis_status bis_dist_spmv_launch(bis_ctx *ctx, bis_dist *d, double *x_ext, double *y, const double *w,
+                                int *n_partials) {
+    BIS_REQUIRE(ctx, d->n_ranks == 1 || d->have_ops, "bis_dist_spmv: no transport set (bis_dist_set_comm / bis_dist_use_rccl)");
+    BIS_REQUIRE(ctx, d->n_ranks == 1 || d->n_send == 0 || d->send_idx, "bis_dist_spmv: send lists not set");
+    int np = 0, tot = 0;
+    const bool exch = d->n_ranks > 1 && (d->n_send > 0 || d->n_halo > 0);
+    if (exch) {
+        if (d->n_send > 0) {
+            const int grid = (int)std::min<int64_t>((d->n_send + 255) / 256, 2048);
+            hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, x_ext, d->send_idx,
+                               d->n_send, d->sendbuf);
+        }
+        BIS_HIP_CHECK(ctx, hipEventRecord(d->ev_packed, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipStreamWaitEvent(d->comm_stream, d->ev_packed, 0));
+        if (d->ops.exchange(d->ops.user, (void *)d->comm_stream, d->sendbuf, d->send_counts.data(),
+                            x_ext + d->n_local, d->recv_counts.data(), d->n_ranks) != 0) {
+            ctx->err = "halo exchange failed";
+            return BIS_ERR_COMM;
+        }
+        BIS_HIP_CHECK(ctx, hipEventRecord(d->ev_halo, d->comm_stream));
+    }
+    // interior rows: no remote column, runs under the exchange
+    bis_status st = bis_spmv_launch(ctx, d->mid, x_ext, y + d->mid_a, w ? w + d->mid_a : nullptr, &np, 0);
+    if (st != BIS_OK) return st;
+    tot += np;
+    if (exch) BIS_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, d->ev_halo, 0));
+    st = bis_spmv_launch(ctx, d->lo, x_ext, y, w, &np, (size_t)tot);
+    if (st != BIS_OK) return st;
+    tot += np;
+    st = bis_spmv_launch(ctx, d->hi, x_ext, y + d->mid_b, w ? w + d->mid_b : nullptr, &np, (size_t)tot);
+    if (st != BIS_OK) return st;
+    tot += np;
+    if (n_partials) *n_partials = tot;
+    return BIS_OK;
+}
+
+int bis_dist_total_blocks(const bis_dist *d) { return d->lo->n_blocks + d->mid->n_blocks + d->hi->n_blocks; }
+int64_t bis_dist_n_local(const bis_dist *d) { return d->n_local; }
+int64_t bis_dist_n_ext(const bis_dist *d) { return d->n_local + d->n_halo; }
+const bis_mat *bis_dist_matrix(const bis_dist *d) { return d->A; }
+bis_status bis_dist_allreduce(bis_ctx *ctx, bis_dist *d, double *buf_dev, int count) {
+    if (d->n_ranks == 1) return BIS_OK;
+    BIS_REQUIRE(ctx, d->have_ops, "bis_dist: no transport set");
+    if (d->ops.allreduce_sum(d->ops.user, (void *)ctx->stream, buf_dev, count) != 0) {
+        ctx->err = "all-reduce failed";
+        return BIS_ERR_COMM;
+    }
+    return BIS_OK;
+}
+
+extern "C" {
+
+bis_status bis_dist_spmv(bis_ctx *ctx, bis_dist *d, double *x_ext, double *y_local) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d && x_ext && y_local, "bis_dist_spmv: bad arguments");
+    return bis_dist_spmv_launch(ctx, d, x_ext, y_local, nullptr, nullptr);
+}
+
+bis_status bis_dist_dot(bis_ctx *ctx, bis_dist *d, const double *a, const double *b,
+                        double *result_dev, double *result_host) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d && result_dev, "bis_dist_dot: bad arguments");
+    bis_status st = bis_dot_dev(ctx, a, b, d->n_local, result_dev);
+    if (st == BIS_OK) st = bis_dist_allreduce(ctx, d, result_dev, 1);
+    if (st != BIS_OK) return st;
+    if (result_host) {
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, result_dev, sizeof(double),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        *result_host = ctx->scalars_host[0];
+    }
+    return BIS_OK;
+}
+
+} // extern "C"

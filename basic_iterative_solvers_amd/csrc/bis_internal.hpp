@@ -41,11 +41,13 @@ constexpr int kMaxReduceBlocks = 2048;
 struct bis_mat {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     bool rp64 = false;        // row_ptr width on the device
+    bool view = false;        // row-range view: row_ptr/col/val belong to another bis_mat
     void *row_ptr = nullptr;  // int32_t[n_rows+1] or int64_t[n_rows+1]
     int32_t *col = nullptr;   // [nnz + pad]
     double *val = nullptr;    // [nnz + pad]
     // SpMV row-block metadata: block k covers rows [blk_row[k], blk_row[k+1])
     int32_t *blk_row = nullptr;
+    int64_t *blk_nnz = nullptr; // row_ptr[blk_row[k]] (saves a dependent load)
     int n_blocks = 0;
     int chunk_nnz = 0;        // nnz budget per block used to build blk_row
     int max_row_nnz = 0;
@@ -134,8 +136,14 @@ bis_status bis_reduce_finish(bis_ctx *ctx, int n_partials, int n_values,
 // make sure ctx->partials holds at least n doubles (stream-synchronising
 // only when it has to grow)
 bis_status bis_ensure_partials(bis_ctx *ctx, size_t n);
+// y = A x; if w != nullptr also partials[partials_off + b] = sum_{r in block b}
+// y[r]*w[r] (n_partials = number written).  The caller sizes ctx->partials.
 bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x,
-                           double *y, const double *w, int *n_partials);
+                           double *y, const double *w, int *n_partials,
+                           size_t partials_off = 0);
+// rows [ra,rb) of A as a matrix sharing A's arrays (y must be offset by ra)
+bis_status bis_mat_row_view(bis_ctx *ctx, const bis_mat *A, int64_t ra,
+                            int64_t rb, bis_mat **out);
 
 // internal launchers shared between translation units
 bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols,

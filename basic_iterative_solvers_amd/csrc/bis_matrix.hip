@@ -31,17 +31,18 @@ __global__ void max_row_kernel(const RP *row_ptr, int64_t n_rows, int *out_max) 
 // blk_row[n_blocks] = n_rows.
 template <typename RP>
 __global__ void row_blocks_kernel(const RP *row_ptr, int64_t n_rows, int n_blocks,
-                                  int64_t chunk, int32_t *blk_row) {
+                                  int64_t chunk, int32_t *blk_row, int64_t *blk_nnz) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > n_blocks) return;
-    if (k == n_blocks) { blk_row[k] = (int32_t)n_rows; return; }
-    const int64_t target = (int64_t)k * chunk;
+    if (k == n_blocks) { blk_row[k] = (int32_t)n_rows; blk_nnz[k] = (int64_t)row_ptr[n_rows]; return; }
+    const int64_t target = (int64_t)row_ptr[0] + (int64_t)k * chunk; // views: row_ptr[0] != 0
     int64_t lo = 0, hi = n_rows; // answer in [0, n_rows]
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         if ((int64_t)row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
     }
     blk_row[k] = (int32_t)lo;
+    blk_nnz[k] = (int64_t)row_ptr[lo];
 }
 
 // ---- generators ---------------------------------------------------------------
@@ -258,16 +259,18 @@ bis_status finalize_t(bis_ctx *ctx, bis_mat *A) {
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     A->max_row_nnz = h_max;
-    int chunk = 4096;
+    int chunk = 2048;
     if (const char *e = getenv("BIS_SPMV_CHUNK")) chunk = std::max(256, atoi(e));
     A->chunk_nnz = chunk;
     int64_t nb = (A->nnz + chunk - 1) / chunk;
     if (nb < 1) nb = 1;
     A->n_blocks = (int)nb;
     if (A->blk_row) hipFree(A->blk_row);
+    if (A->blk_nnz) hipFree(A->blk_nnz);
     BIS_HIP_CHECK(ctx, hipMalloc(&A->blk_row, sizeof(int32_t) * (size_t)(nb + 1)));
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->blk_nnz, sizeof(int64_t) * (size_t)(nb + 1)));
     hipLaunchKernelGGL(row_blocks_kernel<RP>, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0,
-                       ctx->stream, rp, A->n_rows, (int)nb, (int64_t)chunk, A->blk_row);
+                       ctx->stream, rp, A->n_rows, (int)nb, (int64_t)chunk, A->blk_row, A->blk_nnz);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
 }
@@ -299,6 +302,34 @@ bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t n
 
 bis_status bis_mat_finalize(bis_ctx *ctx, bis_mat *A) {
     return A->rp64 ? finalize_t<int64_t>(ctx, A) : finalize_t<int32_t>(ctx, A);
+}
+
+bis_status bis_mat_row_view(bis_ctx *ctx, const bis_mat *A, int64_t ra, int64_t rb, bis_mat **out) {
+    BIS_REQUIRE(ctx, A && out && 0 <= ra && ra <= rb && rb <= A->n_rows, "bis_mat_row_view: bad range");
+    int64_t ends[2] = {0, 0};
+    const size_t w = A->rp64 ? 8 : 4;
+    int64_t a64 = 0, b64 = 0;
+    int32_t a32 = 0, b32 = 0;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(A->rp64 ? (void *)&a64 : (void *)&a32, (char *)A->row_ptr + w * ra, w,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(A->rp64 ? (void *)&b64 : (void *)&b32, (char *)A->row_ptr + w * rb, w,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ends[0] = A->rp64 ? a64 : a32;
+    ends[1] = A->rp64 ? b64 : b32;
+    bis_mat *V = new bis_mat;
+    V->view = true;
+    V->rp64 = A->rp64;
+    V->n_rows = rb - ra;
+    V->n_cols = A->n_cols;
+    V->nnz = ends[1] - ends[0];
+    V->row_ptr = (char *)A->row_ptr + w * ra;
+    V->col = A->col;
+    V->val = A->val;
+    bis_status st = bis_mat_finalize(ctx, V);
+    if (st != BIS_OK) { delete V; return st; }
+    *out = V;
+    return BIS_OK;
 }
 
 extern "C" {
@@ -365,10 +396,13 @@ bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A) {
     hipStreamSynchronize(ctx->stream);
     bis_trsv_plan_destroy(A->plan_fwd);
     bis_trsv_plan_destroy(A->plan_bwd);
-    hipFree(A->row_ptr);
-    hipFree(A->col);
-    hipFree(A->val);
+    if (!A->view) {
+        hipFree(A->row_ptr);
+        hipFree(A->col);
+        hipFree(A->val);
+    }
     hipFree(A->blk_row);
+    hipFree(A->blk_nnz);
     delete A;
     return BIS_OK;
 }

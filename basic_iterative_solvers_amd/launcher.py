@@ -1,0 +1,101 @@
+"""Launcher-side plumbing for the row-partitioned path: torch.distributed is
+used ONLY to (a) route the halo need-lists between ranks once at setup,
+(b) broadcast the RCCL unique id, (c) provide the barrier / max-over-ranks of
+the bench contract, and (d) as a stand-in transport in tests (gloo), where the
+C-ABI's communicator callbacks are served by torch.distributed calls."""
+import ctypes as C
+
+import numpy as np
+
+from . import CommOps, Dist, rccl_unique_id
+
+
+def even_row_starts(n_rows, n_ranks, align=1):
+    """Contiguous split; `align` keeps boundaries on multiples (e.g. nx*ny for z-slabs)."""
+    units = n_rows // align
+    starts = [(units * r // n_ranks) * align for r in range(n_ranks)] + [n_rows]
+    return np.array(starts, dtype=np.int64)
+
+
+def route_need_lists(halo, recv, rank, n_ranks, td, group=None):
+    """Every rank tells each owner which of its columns it needs.  `halo` is
+    the sorted remote-column list, `recv[p]` how many of them rank p owns.
+    Returns (send_counts, send_cols): what the peers need from this rank."""
+    need, off = {}, 0
+    for p in range(n_ranks):
+        need[p] = np.asarray(halo[off:off + int(recv[p])], dtype=np.int32).copy()
+        off += int(recv[p])
+    gathered = [None] * n_ranks
+    td.all_gather_object(gathered, need, group=group)
+    send_counts = np.array([len(gathered[q][rank]) for q in range(n_ranks)], dtype=np.int64)
+    parts = [np.asarray(gathered[q][rank], dtype=np.int32) for q in range(n_ranks)]
+    send_cols = np.concatenate(parts) if parts else np.zeros(0, np.int32)
+    return send_counts, send_cols
+
+
+def route_send_lists(dist_op, td, group=None):
+    halo, recv = dist_op.halo_info()
+    send_counts, send_cols = route_need_lists(halo, recv, dist_op.rank, dist_op.n_ranks, td, group)
+    dist_op.set_send_lists(send_counts, send_cols)
+    return send_counts
+
+
+def setup_rccl(ctx, dist_op, td, group=None):
+    obj = [rccl_unique_id(ctx) if dist_op.rank == 0 else None]
+    td.broadcast_object_list(obj, src=0, group=group)
+    dist_op.use_rccl(obj[0])
+
+
+class _DevArray:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(data=(int(ptr), False), shape=(int(n),), typestr="<f8",
+                                             version=2, strides=None)
+
+
+def torch_comm_ops(td, torch, n_ranks, rank, group=None):
+    """bis_comm_ops served by torch.distributed (tests: gloo on GPU tensors)."""
+
+    def wrap(ptr, n):
+        return torch.as_tensor(_DevArray(ptr, n), device="cuda")
+
+    def allreduce(user, stream, buf, count):
+        try:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                t = wrap(buf, count)
+                td.all_reduce(t, group=group)
+            return 0
+        except Exception as ex:  # noqa
+            print("allreduce callback failed:", ex, flush=True)
+            return 1
+
+    def exchange(user, stream, sendbuf, send_counts, recvbuf, recv_counts, n):
+        try:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                torch.cuda.current_stream().synchronize()
+                reqs, so, ro = [], 0, 0
+                keep = []
+                for p in range(n):
+                    sc, rc = int(send_counts[p]), int(recv_counts[p])
+                    if sc:
+                        t = wrap(sendbuf + 8 * so, sc)
+                        keep.append(t)
+                        reqs.append(td.isend(t, p, group=group))
+                    if rc:
+                        t = wrap(recvbuf + 8 * ro, rc)
+                        keep.append(t)
+                        reqs.append(td.irecv(t, p, group=group))
+                    so += sc
+                    ro += rc
+                for r in reqs:
+                    r.wait()
+                torch.cuda.current_stream().synchronize()
+            return 0
+        except Exception as ex:  # noqa
+            print("exchange callback failed:", ex, flush=True)
+            return 1
+
+    ops = CommOps()
+    ops.user = None
+    ops.allreduce_sum = type(ops.allreduce_sum)(allreduce)
+    ops.exchange = type(ops.exchange)(exchange)
+    return ops

@@ -254,6 +254,96 @@ BIS_API bis_status bis_profile_enable(bis_ctx *ctx, int on);
 BIS_API bis_status bis_profile_read(bis_ctx *ctx, int64_t *spmv_launches,
                                     double *spmv_ms);
 
+/* ---- multi-GPU: 1-D row-block partition --------------
+ * One process per GPU.  Rank g owns the contiguous global rows
+ * [row_starts[g], row_starts[g+1]) of A and the matching slice of every
+ * vector.  The reference has no counterpart (single process, OpenMP): this is
+ * the layer that replaces its shared-memory loops across devices.  Only two
+ * exchange shapes exist: the halo exchange of boundary x entries before an
+ * SpMV and the sum all-reduce of 1-2 scalars after a dot / norm. */
+
+/* Host-only planning step (needs no device; unit-tested on CPU).  Input: the
+ * local rows in CRS with GLOBAL column indices.  Output: the sorted list of
+ * distinct remote columns ("halo", grouped by owner rank because owners hold
+ * contiguous row ranges), how many of them each peer owns (recv_counts
+ * [n_ranks]), and interior[2] = the longest run [a,b) of local rows that
+ * reference no remote column (the part of the SpMV that can overlap the
+ * exchange).  halo_cols may be NULL to query n_halo only; halo_cap is its
+ * capacity. */
+BIS_API bis_status bis_halo_plan(int64_t n_local, const int64_t *row_ptr,
+                                 const int32_t *col_global, int n_ranks,
+                                 int rank, const int64_t *row_starts,
+                                 int64_t *n_halo, int32_t *halo_cols,
+                                 int64_t halo_cap, int64_t *recv_counts,
+                                 int64_t *interior);
+
+typedef struct bis_dist bis_dist;
+
+/* Transport, provided by the launcher or by bis_dist_use_rccl.  Buffers are
+ * DEVICE pointers; the operation must be ordered on `stream` (a hipStream_t).
+ * Return 0 on success. */
+typedef struct {
+    void *user;
+    /* in-place sum all-reduce of `count` doubles */
+    int (*allreduce_sum)(void *user, void *stream, double *buf, int count);
+    /* send send_counts[p] doubles to each peer p from sendbuf (packed in peer
+     * order), receive recv_counts[p] doubles from each peer p into recvbuf
+     * (packed in peer order) */
+    int (*exchange)(void *user, void *stream, const double *sendbuf,
+                    const int64_t *send_counts, double *recvbuf,
+                    const int64_t *recv_counts, int n_ranks);
+} bis_comm_ops;
+
+/* Builds the distributed operator from the local rows (GLOBAL column
+ * indices).  A_local is consumed: its columns are renumbered in place to
+ * [0,n_local) for owned columns and n_local + k for the k-th halo column, and
+ * the handle stays owned by the bis_dist. */
+BIS_API bis_status bis_dist_create(bis_ctx *ctx, bis_mat *A_local, int rank,
+                                   int n_ranks, const int64_t *row_starts,
+                                   bis_dist **out);
+BIS_API bis_status bis_dist_destroy(bis_ctx *ctx, bis_dist *d);
+/* n_local rows / entries owned, n_ext = n_local + n_halo: every vector that
+ * is an SpMV INPUT must be allocated with n_ext entries (the halo tail is
+ * filled by the exchange). */
+BIS_API bis_status bis_dist_vec_len(const bis_dist *d, int64_t *n_local,
+                                    int64_t *n_ext);
+/* What this rank needs: the halo columns (global indices, sorted) and the
+ * per-owner counts.  The launcher routes each owner its sub-list once at
+ * setup (any host-side all-to-all), then calls bis_dist_set_send_lists. */
+BIS_API bis_status bis_dist_halo_info(const bis_dist *d, int64_t *n_halo,
+                                      int32_t *halo_cols, int64_t halo_cap,
+                                      int64_t *recv_counts);
+/* What the peers need from this rank: send_counts[p] global column indices
+ * per peer p, concatenated in peer order (all inside this rank's row range). */
+BIS_API bis_status bis_dist_set_send_lists(bis_ctx *ctx, bis_dist *d,
+                                           const int64_t *send_counts,
+                                           const int32_t *send_cols_global);
+BIS_API bis_status bis_dist_set_comm(bis_ctx *ctx, bis_dist *d,
+                                     const bis_comm_ops *ops);
+/* RCCL transport over xGMI (ncclSend/ncclRecv pairs for the halo, ncclAllReduce
+ * for scalars).  unique_id is the 128-byte ncclUniqueId made by
+ * bis_rccl_unique_id on rank 0 and broadcast by the launcher. */
+BIS_API bis_status bis_rccl_unique_id(bis_ctx *ctx, void *out128);
+BIS_API bis_status bis_dist_use_rccl(bis_ctx *ctx, bis_dist *d,
+                                     const void *unique_id128);
+/* y_local = (A x)_local.  x_ext has n_ext entries (owned part filled by the
+ * caller); the halo exchange runs on a second stream under the interior rows'
+ * SpMV, the boundary rows follow. */
+BIS_API bis_status bis_dist_spmv(bis_ctx *ctx, bis_dist *d, double *x_ext,
+                                 double *y_local);
+/* global dot: local reduction + all-reduce; result_dev (device) always,
+ * result_host if non-NULL (blocking). */
+BIS_API bis_status bis_dist_dot(bis_ctx *ctx, bis_dist *d, const double *a,
+                                const double *b, double *result_dev,
+                                double *result_host);
+/* Fused CG on the distributed operator: same schedule and handle as bis_cg_*
+ * (bis_cg_init / bis_cg_iterate / bis_cg_status / bis_cg_destroy), with the
+ * (Ap,p) all-reduce and the batched {(r,z),(r,r)} all-reduce per iteration.
+ * b, x, A_D are local slices (n_local entries). */
+BIS_API bis_status bis_dist_cg_create(bis_ctx *ctx, bis_dist *d,
+                                      const double *A_D, const double *b,
+                                      double *x, bis_cg **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,41 @@
+"""Row-partitioned path, multi-process.  CPU: gloo, world_size 2 and 3 -- the
+host-side plan (bis_halo_plan), the routing protocol and the distributed CG
+schedule against the single-process oracle.  GPU: the same with the HIP
+kernels and the C-ABI communicator callbacks (ranks share the one GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(world, mode, kind, size, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "dist_worker.py"), mode, kind, str(size)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count(" OK") == world, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 8), (3, "anderson", 6), (2, "anderson", 5)])
+def test_partitioned_cg_gloo_cpu(world, kind, size):
+    launch(world, "cpu", kind, size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 12), (3, "anderson", 7), (1, "hpcg", 8)])
+def test_partitioned_cg_hip(world, kind, size):
+    launch(world, "gpu", kind, size)
