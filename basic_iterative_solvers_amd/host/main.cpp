@@ -1,0 +1,53 @@
+// main.cpp -- CLI driver of the MI355X build; same command line and the same
+// stdout (residual table, summary, timer tree) as the reference's main.cpp.
+//   ./basic_iterative_solvers <matrix.mtx | generator> <-j|-gs|-sgs|-cg|-gm|-bi>
+//        [-p j|gs|bgs|sgs|2st|s2st|ilu0] [-scale 0|1] [-rl N] [-unfused] [-dev K]
+#include "common.hpp"
+#include "methods/bicgstab.hpp"
+#include "methods/cg.hpp"
+#include "methods/gauss_seidel.hpp"
+#include "methods/gmres.hpp"
+#include "methods/jacobi.hpp"
+#include "postprocessing.hpp"
+#include "preprocessing.hpp"
+#include "solver_harness.hpp"
+#include "utilities/utilities.hpp"
+
+static void run(Args *cli_args, Timers *timers) {
+    Solver *solver = nullptr;
+    switch (cli_args->method) {
+    case SolverType::Jacobi: solver = new JacobiSolver(cli_args); break;
+    case SolverType::GaussSeidel: solver = new GaussSeidelSolver(cli_args); break;
+    case SolverType::SymmetricGaussSeidel: solver = new SymmetricGaussSeidelSolver(cli_args); break;
+    case SolverType::ConjugateGradient: solver = new ConjugateGradientSolver(cli_args); break;
+    case SolverType::GMRES: solver = new GMRESSolver(cli_args); break;
+    case SolverType::BiCGSTAB: solver = new BiCGSTABSolver(cli_args); break;
+    }
+    auto A = std::make_unique<MatrixCRS>();
+    if (!make_generated_matrix(cli_args->matrix_file_name, A.get())) {
+        MatrixCOO mtx;
+        try {
+            mtx.read_from_mtx(cli_args->matrix_file_name);
+        } catch (const std::exception &e) {
+            fprintf(stderr, "ERROR: %s\n", e.what());
+            exit(EXIT_FAILURE);
+        }
+        convert_coo_to_crs(&mtx, A.get());
+        A->upload();
+    }
+    TIME(timers, "preprocessing", preprocessing(cli_args, solver, timers, A))
+    TIME(timers, "solve", solve(cli_args, solver, timers))
+    TIME(timers, "postprocessing", postprocessing(cli_args, solver, timers))
+    delete solver;
+}
+
+int main(int argc, char *argv[]) {
+    Timers timers;
+    Args cli_args;
+    parse_cli(&cli_args, argc, argv);
+    bis::init(cli_args.device);
+    TIME(&timers, "total", run(&cli_args, &timers))
+    print_timers(&cli_args, &timers);
+    bis::shutdown();
+    return 0;
+}

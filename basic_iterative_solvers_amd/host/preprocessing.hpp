@@ -1,0 +1,89 @@
+// preprocessing.hpp -- setup phase, reference preprocessing.hpp:26-100:
+// allocate + initialise the solver's vectors, optional symmetric diagonal
+// scaling, split A into its strict triangles and diagonal (on the device for
+// generated matrices, on the host for file input), optional ILU(0), initial
+// residual and stopping criterion.
+#pragma once
+
+#include "common.hpp"
+#include "solver.hpp"
+#include "utilities/LU_factors.hpp"
+
+inline void download_to_host(MatrixCRS *A) { // device-generated matrix -> host arrays (setup only)
+    if (A->row_ptr) return;
+    std::vector<int64_t> rp(A->n_rows + 1);
+    A->row_ptr = new int[A->n_rows + 1];
+    A->col = new int[A->nnz ? A->nnz : 1];
+    A->val = new double[A->nnz ? A->nnz : 1];
+    bis::check(bis_mat_download(bis::ctx(), A->dev, rp.data(), A->col, A->val), "bis_mat_download");
+    for (int i = 0; i <= A->n_rows; ++i) A->row_ptr[i] = (int)rp[i];
+}
+
+inline void scale_mat(MatrixCRS *A, const double *s) { // preprocessing.hpp:15-24
+    for (int r = 0; r < A->n_rows; ++r)
+        for (int i = A->row_ptr[r]; i < A->row_ptr[r + 1]; ++i) A->val[i] *= (s[r] * s[A->col[i]]);
+}
+
+// factor_LU, utilities/LU_factors.hpp:900-934
+inline void factor_LU(Solver *s) {
+    const int N = s->A->n_rows;
+    const bool ilu = s->preconditioner == PrecondType::ILU0;
+    if (ilu) download_to_host(s->A.get());
+    if (!s->A->row_ptr) {
+        // device-resident input: split + diagonal on the device
+        bis_mat *Ls = nullptr, *Us = nullptr;
+        bis::check(bis_mat_split_strict(bis::ctx(), s->A->dev, &Ls, &Us, s->A_D, s->A_D_inv), "bis_mat_split_strict");
+        s->L_strict->adopt(Ls);
+        s->U_strict->adopt(Us);
+        return;
+    }
+    split_LU(s->A.get(), s->L.get(), s->L_strict.get(), s->U.get(), s->U_strict.get());
+    std::vector<double> D(N, 1.0), Dinv(N, 0.0);
+    peel_diag_crs(s->L.get(), D.data(), Dinv.data());
+    peel_diag_crs(s->U.get(), D.data(), Dinv.data());
+    to_device(s->A_D, D.data(), N);
+    to_device(s->A_D_inv, Dinv.data(), N);
+    if (ilu) {
+        // the serial ILU(0) of the reference (factor_ILU0_old); its wired-in
+        // factor_ILU0_new needs the SMAX library (defect 2)
+        std::vector<double> LD(N, 1.0), UD(N, 1.0);
+        factor_ILU0(s->A.get(), s->L_strict.get(), LD.data(), s->U_strict.get(), UD.data());
+        to_device(s->L_D, LD.data(), N);
+        to_device(s->U_D, UD.data(), N);
+    }
+    s->L_strict->upload();
+    s->U_strict->upload();
+}
+
+inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::unique_ptr<MatrixCRS> &A) {
+    (*timers)["preprocessing_init"].start();
+    solver->allocate_structs(A->n_cols);
+    solver->init_structs(A->n_cols);
+    (*timers)["preprocessing_init"].stop();
+    solver->A = std::move(A);
+
+    if (solver->num_scale) { // preprocessing.hpp:39-50: A' = D^-1/2 A D^-1/2, b' = D^-1/2 b
+        const int N = solver->A->n_rows;
+        download_to_host(solver->A.get());
+        std::vector<double> s(N, 0.0);
+        extract_scale(solver->A.get(), s.data());
+        scale_mat(solver->A.get(), s.data());
+        solver->A->upload();
+        to_device(solver->A_D_scale, s.data(), N);
+        // the reference also scales x_0 here, after init_structs has already
+        // copied the unscaled x_0 into the iterate; x_0 is not read again
+        elemwise_mult_vectors(solver->x_0, solver->A_D_scale, solver->x_0, N);
+        elemwise_mult_vectors(solver->b, solver->A_D_scale, solver->b, N);
+    }
+
+    solver->L = std::make_unique<MatrixCRS>();
+    solver->L_strict = std::make_unique<MatrixCRS>();
+    solver->U = std::make_unique<MatrixCRS>();
+    solver->U_strict = std::make_unique<MatrixCRS>();
+    TIME(timers, "preprocessing_factor", factor_LU(solver))
+
+    (*timers)["preprocessing_init"].start();
+    solver->init_residual();
+    solver->init_stopping_criteria();
+    (*timers)["preprocessing_init"].stop();
+}

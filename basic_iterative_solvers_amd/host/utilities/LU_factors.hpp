@@ -1,0 +1,111 @@
+// LU_factors.hpp -- host-side setup (run once): A -> L, L_strict, U, U_strict,
+// diagonal extraction and serial ILU(0), following the reference's
+// utilities/LU_factors.hpp (split_LU :122-309, peel_diag_crs :827-869,
+// extract_scale :880-898, factor_ILU0_old :320-539, factor_LU :900-934).
+// Outputs are bit-identical CRS arrays; the strict parts are uploaded to the
+// device where the triangular solves run.
+#pragma once
+
+#include "../common.hpp"
+#include "../sparse_matrix.hpp"
+
+inline void split_LU(const MatrixCRS *A, MatrixCRS *L, MatrixCRS *L_strict, MatrixCRS *U,
+                     MatrixCRS *U_strict) {
+    const int n = A->n_rows;
+    long cnt[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int k = A->row_ptr[i]; k < A->row_ptr[i + 1]; ++k) {
+            const int c = A->col[k];
+            if (c < i) { ++cnt[0]; ++cnt[1]; }
+            if (c == i) { ++cnt[0]; ++cnt[2]; }
+            if (c > i) { ++cnt[2]; ++cnt[3]; }
+        }
+    MatrixCRS *out[4] = {L, L_strict, U, U_strict};
+    for (int m = 0; m < 4; ++m) {
+        out[m]->free_host();
+        out[m]->n_rows = n; out[m]->n_cols = A->n_cols; out[m]->nnz = (int)cnt[m];
+        out[m]->row_ptr = new int[n + 1];
+        out[m]->col = new int[cnt[m] ? cnt[m] : 1];
+        out[m]->val = new double[cnt[m] ? cnt[m] : 1];
+        out[m]->row_ptr[0] = 0;
+    }
+    int p[4] = {0, 0, 0, 0};
+    auto put = [&](int m, int c, double v) { out[m]->col[p[m]] = c; out[m]->val[p[m]++] = v; };
+    for (int i = 0; i < n; ++i) {
+        for (int k = A->row_ptr[i]; k < A->row_ptr[i + 1]; ++k) {
+            const int c = A->col[k];
+            const double v = A->val[k];
+            if (c < i) { put(0, c, v); put(1, c, v); }
+            if (c == i) { put(0, c, v); put(2, c, v); }
+            if (c > i) { put(2, c, v); put(3, c, v); }
+        }
+        for (int m = 0; m < 4; ++m) out[m]->row_ptr[i + 1] = p[m];
+    }
+}
+
+// D (and 1/D) from the diagonal; the diagonal entry is swapped to the row end.
+inline void peel_diag_crs(MatrixCRS *A, double *D, double *D_inv = nullptr) {
+    for (int r = 0; r < A->n_rows; ++r) {
+        const int start = A->row_ptr[r], last = A->row_ptr[r + 1] - 1;
+        int dj = -1;
+        for (int j = start; j <= last; ++j)
+            if (A->col[j] == r) {
+                dj = j;
+                D[r] = A->val[j];
+                if (std::abs(D[r]) < 1e-16) SanityChecker::zero_diag(r);
+                if (D_inv) D_inv[r] = 1.0 / D[r];
+            }
+        if (dj < 0) SanityChecker::no_diag(r);
+        if (dj != last) { std::swap(A->col[dj], A->col[last]); std::swap(A->val[dj], A->val[last]); }
+    }
+}
+
+inline void extract_scale(MatrixCRS *A, double *D_scale) {
+    for (int r = 0; r < A->n_rows; ++r)
+        for (int j = A->row_ptr[r]; j < A->row_ptr[r + 1]; ++j)
+            if (A->col[j] == r) {
+                if (std::abs(A->val[j]) < 1e-16) SanityChecker::zero_diag(r);
+                D_scale[r] = 1.0 / std::sqrt(std::abs(A->val[j]));
+            }
+}
+
+// Serial ILU(0) restricted to A's pattern (IKJ, ascending dependencies).
+// L_strict / U_strict must already hold A's strict parts' sizes (split_LU);
+// they are overwritten with the factors (ascending columns), L_D = 1, U_D = u_ii.
+inline void factor_ILU0(const MatrixCRS *A, MatrixCRS *L_strict, double *L_D, MatrixCRS *U_strict,
+                        double *U_D) {
+    const int n = A->n_rows;
+    std::vector<double> w(n, 0.0);
+    std::vector<int> idx;
+    int lp = 0, up = 0;
+    L_strict->row_ptr[0] = 0;
+    U_strict->row_ptr[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        idx.clear();
+        for (int p = A->row_ptr[i]; p < A->row_ptr[i + 1]; ++p) { w[A->col[p]] = A->val[p]; idx.push_back(A->col[p]); }
+        std::sort(idx.begin(), idx.end());
+        for (int k : idx) {
+            if (k >= i) break;
+            const double pivot = U_D[k];
+            if (std::abs(pivot) < 1e-16) continue;
+            const double factor = w[k] / pivot;
+            w[k] = factor;
+            for (int p = U_strict->row_ptr[k]; p < U_strict->row_ptr[k + 1]; ++p) {
+                const int j = U_strict->col[p];
+                if (w[j] != 0.0) w[j] -= factor * U_strict->val[p];
+            }
+        }
+        double u_diag = 0.0;
+        for (int j : idx) {
+            if (j < i) { L_strict->col[lp] = j; L_strict->val[lp++] = w[j]; }
+            else if (j == i) u_diag = w[j];
+            else { U_strict->col[up] = j; U_strict->val[up++] = w[j]; }
+        }
+        if (std::abs(u_diag) < ILU0_PIVOT_TOLERANCE) u_diag = (u_diag >= 0 ? 1.0 : -1.0) * ILU0_PIVOT_REPLACEMENT;
+        U_D[i] = u_diag;
+        L_D[i] = 1.0;
+        L_strict->row_ptr[i + 1] = lp;
+        U_strict->row_ptr[i + 1] = up;
+        for (int j : idx) w[j] = 0.0;
+    }
+}

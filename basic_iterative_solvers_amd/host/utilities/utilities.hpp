@@ -1,0 +1,148 @@
+// utilities.hpp -- CLI, timer-tree printing and COO->CRS conversion
+// (reference utilities/utilities.hpp:12-108, :154-324, :326-367).  Same flags
+// and the same output layout.  Extra, MI355X-specific: the <matrix> argument
+// may be a generator string instead of a file (the reference does the same
+// with SCAMAC strings when built with -DUSE_SCAMAC, main.cpp:48-54):
+//     hpcg:N | hpcg:NX,NY,NZ | anderson:L[,shift=S][,W=w][,t=t][,seed=k]
+// and `-unfused` / `-dev K` select the kernel-by-kernel CG and the device.
+#pragma once
+
+#include "../common.hpp"
+#include "../sparse_matrix.hpp"
+
+inline void parse_cli(Args *a, int argc, char *argv[]) {
+    if (argc < 3) {
+        printf("ERROR: parse_cli: Not enough arguments given. A call should contain:"
+               "\n%s <matrix> <method> [extra_features]\n", argv[0]);
+        exit(EXIT_FAILURE);
+    }
+    a->matrix_file_name = argv[1];
+    const std::string st = argv[2];
+    if (st == "-j") a->method = SolverType::Jacobi;
+    else if (st == "-gs") a->method = SolverType::GaussSeidel;
+    else if (st == "-sgs") a->method = SolverType::SymmetricGaussSeidel;
+    else if (st == "-cg") a->method = SolverType::ConjugateGradient;
+    else if (st == "-gm") a->method = SolverType::GMRES;
+    else if (st == "-bi") a->method = SolverType::BiCGSTAB;
+    else {
+        printf("ERROR: parse_cli: Please choose an available solver:"
+               "\n-j (Jacobi)\n-gs (Gauss-Seidel)\n-sgs (Symmetric Gauss-Seidel)"
+               "\n-gm ([Preconditioned] GMRES)\n-cg ([Preconditioned] Conjugate Gradient)"
+               "\n-bi ([Preconditioned] BiCGSTAB)\n");
+        exit(EXIT_FAILURE);
+    }
+    for (int i = 3; i < argc; ++i) {
+        const std::string arg = argv[i];
+        if (arg == "-p") {
+            if (i + 1 >= argc) {
+                printf("ERROR: parse_cli: Not enough arguments given. Some extra features need "
+                       "additional arguments. Example:\n%s <matrix> <method> -p gs\n", argv[0]);
+                exit(EXIT_FAILURE);
+            }
+            const std::string pt = argv[++i];
+            static const std::map<std::string, PrecondType> pcs = {
+                {"j", PrecondType::Jacobi}, {"gs", PrecondType::GaussSeidel},
+                {"bgs", PrecondType::BackwardsGaussSeidel}, {"sgs", PrecondType::SymmetricGaussSeidel},
+                {"2st", PrecondType::TwoStageGS}, {"s2st", PrecondType::SymmetricTwoStageGS},
+                {"ilu0", PrecondType::ILU0}};
+            auto it = pcs.find(pt);
+            if (it == pcs.end()) {
+                fprintf(stderr, "ERROR: assign_cli_inputs: Please choose an available preconditioner type: "
+                                "\n-p j (Jacobi)\n-p gs (Gauss-Seidel)\n-p bgs (Backwards Gauss-Seidel)"
+                                "\n-p sgs (Symmetric Gauss-Seidel)\n-p 2st (2 Stage Gauss-Seidel)"
+                                "\n-p s2st (Symmetric 2 Stage Gauss-Seidel)\n-p ilu0 (Incomplete LU with 0 fill-in)\n");
+                exit(EXIT_FAILURE);
+            }
+            a->preconditioner = it->second;
+        } else if (arg == "-scale" && i + 1 < argc) a->num_scale = (bool)atoi(argv[++i]);
+        else if (arg == "-rl" && i + 1 < argc) a->restart_length = atoi(argv[++i]);
+        else if (arg == "-unfused") a->unfused = true;
+        else if (arg == "-dev" && i + 1 < argc) a->device = atoi(argv[++i]);
+        else std::cout << "ERROR: assign_cli_inputs: Arguement \"" << arg << "\" not recongnized." << std::endl;
+    }
+}
+
+inline void print_timers(Args *cli_args, Timers *timers) {
+    auto line = [&](const char *label, const char *key) {
+        std::cout << std::left << std::setw(25) << label << std::right << std::setw(30)
+                  << (*timers)[key].get_wtime() << "[s]" << std::endl;
+    };
+    const SolverType m = cli_args->method;
+    std::cout << std::endl << std::scientific << std::setprecision(3);
+    std::cout << "+---------------------------------------------------------+" << std::endl;
+    line("Total elapsed time: ", "total");
+    line("| Preprocessing time: ", "preprocessing");
+    line("| | Init time: ", "preprocessing_init");
+    line("| | Factor time: ", "preprocessing_factor");
+    line("| Solve time: ", "solve");
+    line("| | Iterate time: ", "iterate");
+    line("| | | SpMV time: ", "spmv");
+    line("| | | Precond. time: ", "precond");
+    if (m == SolverType::Jacobi) line("| | | Normalize time: ", "normalize");
+    else if (m == SolverType::GaussSeidel || m == SolverType::SymmetricGaussSeidel) {
+        line("| | | Sum time: ", "sum");
+        line("| | | SpTRSV time: ", "sptrsv");
+    } else if (m == SolverType::ConjugateGradient || m == SolverType::BiCGSTAB) {
+        line("| | | Dot time: ", "dot");
+        line("| | | Sum time: ", "sum");
+    } else if (m == SolverType::GMRES) {
+        line("| | | Orthog. time: ", "orthog");
+        line("| | | | Dot time: ", "dot");
+        line("| | | | Sum time: ", "sum");
+        line("| | | | Norm time: ", "norm");
+        line("| | | | Scale time: ", "scale");
+        line("| | | Least Sq. time: ", "least_sq");
+        line("| | | | DGEMM time: ", "dgemm");
+        line("| | | Update g time: ", "update_g");
+        line("| | | | DGEMV time: ", "dgemv");
+    }
+    line("| | Sample time: ", "sample");
+    line("| | Exchange time: ", "exchange");
+    if (m == SolverType::GMRES) line("| | Restart time: ", "restart");
+    line("| | Save x* time: ", "save_x_star");
+    line("| Postprocessing time: ", "postprocessing");
+    std::cout << "+---------------------------------------------------------+" << std::endl << std::endl;
+}
+
+inline void convert_coo_to_crs(MatrixCOO *coo, MatrixCRS *crs) {
+    crs->n_rows = coo->n_rows; crs->n_cols = coo->n_cols; crs->nnz = coo->nnz;
+    crs->row_ptr = new int[crs->n_rows + 1]();
+    crs->col = new int[crs->nnz ? crs->nnz : 1];
+    crs->val = new double[crs->nnz ? crs->nnz : 1];
+    for (int k = 0; k < crs->nnz; ++k) { crs->col[k] = coo->J[k]; crs->val[k] = coo->values[k]; ++crs->row_ptr[coo->I[k] + 1]; }
+    for (int r = 0; r < crs->n_rows; ++r) crs->row_ptr[r + 1] += crs->row_ptr[r];
+    if (crs->row_ptr[crs->n_rows] != crs->nnz) { printf("ERROR: converting to CRS.\n"); exit(1); }
+}
+
+// generator strings -> device-resident matrix (no host copy)
+inline bool make_generated_matrix(const std::string &spec, MatrixCRS *A) {
+    auto split = [](const std::string &s, char d) {
+        std::vector<std::string> out; std::stringstream ss(s); std::string t;
+        while (std::getline(ss, t, d)) out.push_back(t);
+        return out;
+    };
+    const auto head = split(spec, ':');
+    if (head.size() != 2) return false;
+    bis_mat *m = nullptr;
+    const auto f = split(head[1], ',');
+    if (head[0] == "hpcg") {
+        long nx = atol(f[0].c_str()), ny = nx, nz = nx;
+        if (f.size() == 3) { ny = atol(f[1].c_str()); nz = atol(f[2].c_str()); }
+        bis::check(bis_mat_gen_hpcg(bis::ctx(), nx, ny, nz, 0, nx * ny * nz, &m), "bis_mat_gen_hpcg");
+    } else if (head[0] == "anderson") {
+        const long L = atol(f[0].c_str());
+        double t = 1.0, W = 5.0, shift = 0.0;
+        unsigned long long seed = 1;
+        for (size_t i = 1; i < f.size(); ++i) {
+            const auto kv = split(f[i], '=');
+            if (kv.size() != 2) continue;
+            if (kv[0] == "shift") shift = atof(kv[1].c_str());
+            else if (kv[0] == "W") W = atof(kv[1].c_str());
+            else if (kv[0] == "t") t = atof(kv[1].c_str());
+            else if (kv[0] == "seed") seed = strtoull(kv[1].c_str(), nullptr, 10);
+        }
+        bis::check(bis_mat_gen_anderson(bis::ctx(), L, t, W, shift, seed, 0, L * L * L, &m), "bis_mat_gen_anderson");
+    } else return false;
+    A->adopt(m);
+    return true;
+}

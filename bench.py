@@ -42,27 +42,41 @@ def parse():
 
 
 def cpu_baseline(size, precond, iters):
-    """Oracle (OpenMP port of the reference's CG loop) on the host cores."""
-    from oracle.pyoracle import Oracle
-    cores = os.cpu_count() or 1
-    threads = int(os.environ.get("BIS_CPU_THREADS", min(cores, 64)))
-    os.environ["OMP_NUM_THREADS"] = str(threads)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
-    orc = Oracle()
+    """The reference's CG on the host cores of this box.
+
+    kind "reference": oracle/_ref (the reference's own ConjugateGradientSolver,
+    compiled from its sources by oracle/Makefile and shipped prebuilt), timed by
+    the reference's own timer tree (iterate + sample).  Falls back to kind
+    "port" (the oracle's OpenMP restatement) if the prebuilt reference is absent.
+    """
+    import numpy as np
+
+    from oracle import pyoracle
+    threads = int(os.environ.get("BIS_CPU_THREADS", "16"))  # the box's CPU share for one GPU
+    pyoracle.set_omp_threads(threads)
+    orc = pyoracle.Oracle()
     t0 = time.time()
     A = orc.gen_hpcg(size)
     gen_s = time.time() - t0
-    import numpy as np
     D = np.full(A.n_rows, 26.0) if precond == "j" else None
-    if iters <= 0:
-        # one probe iteration, then size the sample for ~15 s of CPU work
-        _, s1 = orc.cg_run(A, 1, D)
+    _, s1 = orc.cg_run(A, 1, D)
+    if iters <= 0:  # size the sample for ~15 s of CPU work
         iters = int(max(3, min(200, 15.0 / max(s1, 1e-3))))
+    if pyoracle.Ref.available() and A.nnz < 2 ** 31 - 1 and os.environ.get("BIS_CPU_KIND") != "port":
+        ref = pyoracle.Ref()
+        r = ref.solve(A, "cg", "j" if precond == "j" else "none", max_iters=iters, tol=1e-300)
+        secs = r["iterate_s"] + r["sample_s"]
+        n_it = r["iters"]
+        return dict(value=n_it / secs, unit="CG iterations/s", cores=threads, kind="reference",
+                    sample=f"HPCG {size}^3 ({A.nnz} nnz), {n_it} CG iterations of the reference's own "
+                           f"ConjugateGradientSolver (oracle/_ref, g++ -O3 -march=native -fopenmp, "
+                           f"{threads} OpenMP threads), iterate+sample time from its timer tree; "
+                           f"SpMV share {r['spmv_s'] / secs:.2f}",
+                    ms_per_step=1e3 * secs / n_it), r["hist"]
     hist, secs = orc.cg_run(A, iters, D)
-    return dict(value=iters / secs, unit="CG iterations/s", cores=orc.num_threads(), kind="port",
+    return dict(value=iters / secs, unit="CG iterations/s", cores=threads, kind="port",
                 sample=f"HPCG {size}^3 ({A.nnz} nnz), {iters} CG iterations of the oracle's OpenMP "
-                       f"port (oracle/bis_oracle.c orc_cg_run), {orc.num_threads()} threads, "
+                       f"port (oracle/bis_oracle.c orc_cg_run), {threads} threads, "
                        f"matrix generated on host in {gen_s:.1f} s",
                 ms_per_step=1e3 * secs / iters), hist
 
@@ -82,7 +96,7 @@ def main():
 
     from basic_iterative_solvers_amd import Context
 
-    if world > 1:
+    if world > 1 or os.environ.get("BIS_FORCE_DIST") == "1":
         from basic_iterative_solvers_amd.dist_bench import run_distributed
         return run_distributed(args, rank, world, local_rank)
 

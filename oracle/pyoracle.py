@@ -21,6 +21,12 @@ i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
+def set_omp_threads(n):
+    """Set the OpenMP team size of the (single) libgomp the oracle and the
+    compiled reference share -- OMP_NUM_THREADS is read only at load time."""
+    C.CDLL("libgomp.so.1").omp_set_num_threads(C.c_int(int(n)))
+
+
 def build(ref=True):
     """Compile the oracle (and, when /root/reference exists, oracle/_ref)."""
     subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
@@ -520,7 +526,7 @@ class Ref:
         hist = np.zeros(2 * 1000)
         x_star = np.zeros(A.n_rows)
         oi = np.zeros(3, dtype=np.int32)
-        od = np.zeros(2)
+        od = np.zeros(5)
         rp = A.rp32
         rc = self.lib.ref_solve(C.c_int(A.n_rows), C.c_int(A.nnz), rp.ctypes,
                                 A.col.ctypes, A.val.ctypes,
@@ -533,4 +539,5 @@ class Ref:
             raise RuntimeError(f"ref_solve failed: {rc}")
         return dict(iters=int(oi[0]), hist=hist[:oi[1]].copy(),
                     converged=bool(oi[2]), stopping=od[0],
-                    final_true_residual=od[1], x=x_star)
+                    final_true_residual=od[1], x=x_star, iterate_s=od[2],
+                    sample_s=od[3], spmv_s=od[4])

@@ -272,7 +272,8 @@ REF_API void ref_factor_ilu0(int n, int nnz, const int *rp, const int *col,
 // classes.  ilu_real != 0 swaps in factor_ILU0_old for the SMAX-only
 // factor_ILU0_new (SURVEY.md section 5 defect 2 / section 8c).
 // out_i: [iters (as printed), n_hist, converged]; out_d: [stopping, final
-// true residual].  hist must hold 2*MAX_ITERS doubles, x_star n doubles.
+// true residual, iterate seconds, sample seconds, spmv seconds] (the last three
+// from the reference's Timers).  hist must hold 2*MAX_ITERS doubles, x_star n doubles.
 REF_API int ref_solve(int n, int nnz, const int *rp, const int *col,
                       const double *val, int solver_type, int precond,
                       int restart_len, int num_scale, int max_iters,
@@ -349,6 +350,9 @@ REF_API int ref_solve(int n, int nnz, const int *rp, const int *col,
     out_i[2] = solver->convergence_flag ? 1 : 0;
     out_d[0] = solver->stopping_criteria;
     out_d[1] = solver->collected_residual_norms[count + 1]; // solver.hpp:158
+    out_d[2] = (double)timers->iterate_time->get_wtime();   // the reference's own timer tree
+    out_d[3] = (double)timers->sample_time->get_wtime();
+    out_d[4] = (double)timers->spmv_time->get_wtime();
     std::memcpy(x_star, solver->x_star, sizeof(double) * n);
     delete solver;
     return 0;
