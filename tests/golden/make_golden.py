@@ -119,6 +119,15 @@ def histories(ref, orc, mats):
                          stopping=r["stopping"],
                          final_true_residual=r["final_true_residual"],
                          hist=[float(v) for v in r["hist"]])
+            # How far is this history independent of rounding?  The oracle is the same
+            # algorithm with different rounding (fma row sums vs the reference's
+            # re-associated SIMD sums): the first index where the two part by more
+            # than 1e-9 r0 bounds what any other implementation can be compared on.
+            o_all = orc.solve(A, solver, pc, **kw)
+            n_all = min(len(o_all["hist"]), len(r["hist"]))
+            d_all = np.abs(o_all["hist"][:n_all] - r["hist"][:n_all]) / r["hist"][0]
+            bad = np.nonzero(~(d_all <= 1e-9))[0]
+            entry["stable_len"] = int(bad[0]) if len(bad) else int(n_all)
             if solver == "gm":
                 # GMRES restarts read one word past `y` in the reference
                 # (SURVEY.md section 5 defect 1).  Keep a restarted history
@@ -130,10 +139,15 @@ def histories(ref, orc, mats):
                 n = min(len(o["hist"]), len(r["hist"]))
                 dev = np.max(np.abs(o["hist"][:n] - r["hist"][:n])) / r["hist"][0]
                 finite = bool(np.all(np.isfinite(r["hist"])))
-                clean = dev < 1e-12 and finite
+                same_len = len(o["hist"]) == len(r["hist"])
+                clean = dev < 1e-12 and finite and same_len
                 entry["restart_clean"] = bool(clean)
                 if not clean:
-                    entry["hist"] = entry["hist"][: min(m + 1, n)]
+                    # agreeing prefix if the two only stop at different rounding-level
+                    # iterations, else the part before the first restart
+                    keep = n if dev < 1e-12 else min(m + 1, n)
+                    entry["hist"] = entry["hist"][:keep]
+                    entry["stable_len"] = min(entry["stable_len"], keep)
                     entry["iters"] = None
                     entry["converged"] = None
                     entry["final_true_residual"] = None
