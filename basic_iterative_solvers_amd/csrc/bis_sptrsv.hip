@@ -27,6 +27,7 @@
 #include "bis_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 struct bis_trsv_plan {
     int32_t *perm = nullptr; // device, rows sorted by level
@@ -34,6 +35,7 @@ struct bis_trsv_plan {
     unsigned *ticket = nullptr;
     int n_levels = 0;
     int64_t n = 0;
+    int64_t max_level_width = 0;
 };
 
 void bis_trsv_plan_destroy(bis_trsv_plan *p) {
@@ -49,6 +51,7 @@ namespace {
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
 constexpr int kTrsvT = 256;
+constexpr int kBatch = 8; // dependencies polled per round trip
 
 __global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned long long *xs, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -78,12 +81,26 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
             double acc = 0.0;
             bool done = false;
             while (!done) {
+                // Poll up to kBatch pending dependencies with independent loads (one
+                // memory round trip for the batch, not one per dependency), then
+                // consume the ready prefix IN ORDER so the sum keeps CRS order.
                 while (k < e) {
-                    const unsigned long long bits = __hip_atomic_load(
-                        &xs[col[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (bits == kSentinel) break;
-                    acc = fma(val[k], __longlong_as_double((long long)bits), acc);
-                    ++k;
+                    unsigned long long bits[kBatch];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j)
+                        bits[j] = (k + j < e) ? __hip_atomic_load(&xs[col[k + j]], __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT)
+                                              : 0ull;
+                    int ready = 0;
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) {
+                        if (ready == j && k + j < e && bits[j] != kSentinel) {
+                            acc = fma(val[k + j], __longlong_as_double((long long)bits[j]), acc);
+                            ready = j + 1;
+                        }
+                    }
+                    k += ready;
+                    if (ready < kBatch) break; // hit a pending dependency (or the row end)
                 }
                 if (k == e) {
                     const double v = (rhs - acc) / d;
@@ -93,7 +110,7 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
                     x[r] = __longlong_as_double((long long)out);
                     done = true;
                 } else {
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
         }
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
 // Host analysis: levels and the level-sorted permutation.
 template <typename RP>
 void build_perm(const RP *rp, const int32_t *col, int64_t n, bool backward,
-                std::vector<int32_t> &perm, int &n_levels) {
+                std::vector<int32_t> &perm, int &n_levels, int64_t &max_width) {
     std::vector<int32_t> level(n, 0);
     int maxl = 0;
     if (!backward) {
@@ -126,6 +143,8 @@ void build_perm(const RP *rp, const int32_t *col, int64_t n, bool backward,
     for (int64_t r = 0; r < n; ++r) start[level[r] + 1]++;
     for (int l = 0; l < n_levels; ++l) start[l + 1] += start[l];
     perm.resize(n);
+    max_width = 0;
+    for (int l = 0; l < n_levels; ++l) max_width = std::max<int64_t>(max_width, start[l + 1] - start[l]);
     for (int64_t r = 0; r < n; ++r) perm[start[level[r]]++] = (int32_t)r;
 }
 
@@ -158,7 +177,7 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
     std::vector<int32_t> perm;
     bis_trsv_plan *p = new bis_trsv_plan;
     p->n = n;
-    build_perm(rp.data(), col.data(), n, backward, perm, p->n_levels);
+    build_perm(rp.data(), col.data(), n, backward, perm, p->n_levels, p->max_level_width);
     hipError_t e = hipMalloc(&p->perm, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1));
     if (e == hipSuccess) e = hipMalloc(&p->xs, sizeof(double) * (size_t)std::max<int64_t>(n, 1));
     if (e == hipSuccess) e = hipMalloc(&p->ticket, sizeof(unsigned) * 4);
@@ -192,7 +211,16 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     BIS_HIP_CHECK(ctx, hipMemsetAsync(p->ticket, 0, sizeof(unsigned), ctx->stream));
     // persistent grid: resident by construction (<= 4 workgroups of 256 per CU)
     const int64_t n_tickets = (n + kTrsvT - 1) / kTrsvT;
-    const int grid = (int)std::min<int64_t>(n_tickets, (int64_t)ctx->n_cus * 4);
+    // Only ~one level is runnable at a time: keep a few of the widest levels
+    // resident, at most one workgroup per CU -- idle pollers slow the hand-offs
+    // (measured: HPCG-128 4.6 ms at 64-128 workgroups, 9.3 ms at 512, 22 ms at
+    // 1024; Anderson-256 4.5 ms at 256, 13.5 ms at 1024).
+    int64_t want = (4 * p->max_level_width + kTrsvT - 1) / kTrsvT + 1;
+    want = std::min<int64_t>(want, ctx->n_cus);
+    static const int env_grid = getenv("BIS_TRSV_GRID") ? atoi(getenv("BIS_TRSV_GRID")) : 0;
+    if (env_grid > 0) want = env_grid;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_tickets, want),
+                                                                 (int64_t)ctx->n_cus * 4));
     if (T->rp64)
         hipLaunchKernelGGL(sptrsv_syncfree_kernel<int64_t>, dim3(grid), dim3(kTrsvT), 0, ctx->stream,
                            (const int64_t *)T->row_ptr, T->col, T->val, p->perm, n, D, b, x,
