@@ -42,6 +42,7 @@ struct bis_cg {
     int64_t n = 0;
     double *p = nullptr, *r = nullptr, *z = nullptr, *tmp = nullptr;
     double *sc = nullptr;   // device scalars, see enum below
+    double *pap_stage = nullptr; // [kPapBlocks] stage-1 sums of the SpMV's fused partials
     int *flags = nullptr;   // device: [0] iters, [1] done, [2] converged
     double *hist = nullptr; // device residual history
     int hist_cap = 0;
@@ -116,14 +117,25 @@ __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, const double *
     if (threadIdx.x == 0) { partials[blockIdx.x] = s0; partials[stride + blockIdx.x] = s1; }
 }
 
-// sc[S_PAP] = sum of the SpMV's fused partials
-__global__ __launch_bounds__(1024) void cg_finish_pap_kernel(const double *partials, int n_partials,
-                                                             double *sc, const int *flags) {
-    __shared__ double lds[16];
+// sc[S_PAP] = sum of the SpMV's fused per-row-block partials (one per 2048
+// non-zeros: 219k of them on HPCG-256), in two fixed-order stages.
+constexpr int kPapBlocks = 128;
+__global__ __launch_bounds__(256) void cg_finish_pap_stage1(const double *partials, int n_partials,
+                                                            double *stage, const int *flags) {
+    __shared__ double lds[4];
     if (flags[1]) return;
+    const int per = (n_partials + kPapBlocks - 1) / kPapBlocks;
+    const int lo = blockIdx.x * per, hi = min(lo + per, n_partials);
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n_partials; i += 1024) acc += partials[i];
-    const double s = block_sum<1024>(acc, lds);
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) acc += partials[i];
+    const double s = block_sum<256>(acc, lds);
+    if (threadIdx.x == 0) stage[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(kPapBlocks) void cg_finish_pap_stage2(const double *stage, double *sc,
+                                                                   const int *flags) {
+    __shared__ double lds[kPapBlocks / 64];
+    if (flags[1]) return;
+    const double s = block_sum<kPapBlocks>(stage[threadIdx.x], lds);
     if (threadIdx.x == 0) sc[S_PAP] = s;
 }
 
@@ -213,6 +225,7 @@ static bis_status cg_create_common(bis_ctx *ctx, bis_dist *dist, const bis_mat *
     if (st == BIS_OK && A_D) st = bis_vec_alloc(ctx, cg->n, &cg->z);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->n, &cg->tmp);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, S_COUNT, &cg->sc);
+    if (st == BIS_OK) st = bis_vec_alloc(ctx, 256, &cg->pap_stage);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->hist_cap, &cg->hist);
     if (st == BIS_OK && hipMalloc(&cg->flags, sizeof(int) * 4) != hipSuccess) st = BIS_ERR_HIP;
     if (st != BIS_OK) { bis_cg_destroy(ctx, cg); return st; }
@@ -245,6 +258,7 @@ bis_status bis_cg_destroy(bis_ctx *ctx, bis_cg *cg) {
     if (cg->z != cg->r) hipFree(cg->z);
     hipFree(cg->tmp);
     hipFree(cg->sc);
+    hipFree(cg->pap_stage);
     hipFree(cg->hist);
     hipFree(cg->flags);
     delete cg;
@@ -305,8 +319,10 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
         if (cg->dist) st = bis_dist_spmv_launch(ctx, cg->dist, cg->p, cg->tmp, cg->p, &n_part);
         else st = bis_spmv_launch(ctx, cg->A, cg->p, cg->tmp, cg->p, &n_part);
         if (st != BIS_OK) return st;
-        hipLaunchKernelGGL(cg_finish_pap_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->partials,
-                           n_part, cg->sc, cg->flags);
+        hipLaunchKernelGGL(cg_finish_pap_stage1, dim3(kPapBlocks), dim3(256), 0, ctx->stream,
+                           ctx->partials, n_part, cg->pap_stage, cg->flags);
+        hipLaunchKernelGGL(cg_finish_pap_stage2, dim3(1), dim3(kPapBlocks), 0, ctx->stream,
+                           cg->pap_stage, cg->sc, cg->flags);
         if (cg->dist) {
             st = bis_dist_allreduce(ctx, cg->dist, cg->sc + S_PAP, 1);
             if (st != BIS_OK) return st;
