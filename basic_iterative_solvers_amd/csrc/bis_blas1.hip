@@ -5,6 +5,8 @@
 // workgroups with a grid-stride loop (cdna_hip_programming.md Guideline 11/13).
 #include "bis_internal.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kEwThreads = 256;
@@ -171,8 +173,31 @@ bis_status bis_ensure_partials(bis_ctx *ctx, size_t n) {
     return BIS_OK;
 }
 
+bis_options &bis_opts() {
+    static bis_options o = [] {
+        bis_options v;
+        if (const char *e = getenv("BIS_SPMV_VARIANT")) v.spmv_variant = atoi(e);
+        if (const char *e = getenv("BIS_SPMV_WINDOW")) v.spmv_window = atoi(e);
+        if (const char *e = getenv("BIS_SPMV_CHUNK")) v.spmv_chunk = atoi(e);
+        if (const char *e = getenv("BIS_TRSV_GRID")) v.trsv_grid = atoi(e);
+        return v;
+    }();
+    return o;
+}
+
 // ---- context ------------------------------------------------------------------
 extern "C" {
+
+bis_status bis_set_option(const char *name, int value) {
+    if (!name) return BIS_ERR_INVALID;
+    bis_options &o = bis_opts();
+    if (!strcmp(name, "spmv_variant")) o.spmv_variant = value;
+    else if (!strcmp(name, "spmv_window")) o.spmv_window = value;
+    else if (!strcmp(name, "spmv_chunk")) o.spmv_chunk = value;
+    else if (!strcmp(name, "trsv_grid")) o.trsv_grid = value;
+    else return BIS_ERR_INVALID;
+    return BIS_OK;
+}
 
 int bis_abi_version(void) { return 1; }
 

@@ -36,7 +36,19 @@ struct bis_ctx {
     size_t prof_used = 0;
 };
 
+// Tuning knobs (bis_set_option / BIS_* environment variables at first use).
+struct bis_options {
+    int spmv_variant = -1; // -1: default (40 = 256 threads, 4 staged vectors)
+    int spmv_window = -1;  // -1: default (0: CRS gather kernel)
+    int spmv_chunk = -1;   // -1: default (2048 non-zeros per row block)
+    int trsv_grid = -1;    // -1: automatic
+};
+bis_options &bis_opts();
+
 constexpr int kMaxReduceBlocks = 2048;
+constexpr int kWinMaxTiles = 128; // x window: at most 128 tiles of 16 columns (16 KiB of LDS)
+constexpr int kWinTile = 16;
+constexpr int kWinTileLog = 4;
 
 struct bis_mat {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
@@ -48,6 +60,15 @@ struct bis_mat {
     // SpMV row-block metadata: block k covers rows [blk_row[k], blk_row[k+1])
     int32_t *blk_row = nullptr;
     int64_t *blk_nnz = nullptr; // row_ptr[blk_row[k]] (saves a dependent load)
+    // x-window acceleration structure (bis_spmv.hip): per row block the sorted
+    // list of 16-column tiles of x it touches, and per non-zero a 16-bit offset
+    // into that window (replaces the 32-bit col in the SpMV stream)
+    uint16_t *loc = nullptr;    // [nnz_range + pad], index k - loc_base
+    int32_t *tiles = nullptr;   // [n_blocks * kWinMaxTiles]
+    int32_t *tile_cnt = nullptr; // [n_blocks]
+    int64_t loc_base = 0;
+    int max_tiles = 0;
+    bool win_ok = false;
     int n_blocks = 0;
     int chunk_nnz = 0;        // nnz budget per block used to build blk_row
     int max_row_nnz = 0;
@@ -149,4 +170,5 @@ bis_status bis_mat_row_view(bis_ctx *ctx, const bis_mat *A, int64_t ra,
 bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols,
                          int64_t nnz, bool rp64, bis_mat **out);
 bis_status bis_mat_finalize(bis_ctx *ctx, bis_mat *A);
+bis_status bis_spmv_build_window(bis_ctx *ctx, bis_mat *A);
 void bis_trsv_plan_destroy(bis_trsv_plan *p);

@@ -259,8 +259,7 @@ bis_status finalize_t(bis_ctx *ctx, bis_mat *A) {
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     A->max_row_nnz = h_max;
-    int chunk = 2048;
-    if (const char *e = getenv("BIS_SPMV_CHUNK")) chunk = std::max(256, atoi(e));
+    int chunk = bis_opts().spmv_chunk > 0 ? std::max(256, bis_opts().spmv_chunk) : 2048;
     A->chunk_nnz = chunk;
     int64_t nb = (A->nnz + chunk - 1) / chunk;
     if (nb < 1) nb = 1;
@@ -272,7 +271,7 @@ bis_status finalize_t(bis_ctx *ctx, bis_mat *A) {
     hipLaunchKernelGGL(row_blocks_kernel<RP>, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0,
                        ctx->stream, rp, A->n_rows, (int)nb, (int64_t)chunk, A->blk_row, A->blk_nnz);
     BIS_HIP_CHECK(ctx, hipGetLastError());
-    return BIS_OK;
+    return bis_spmv_build_window(ctx, A);
 }
 
 } // namespace
@@ -403,7 +402,19 @@ bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A) {
     }
     hipFree(A->blk_row);
     hipFree(A->blk_nnz);
+    hipFree(A->loc);
+    hipFree(A->tiles);
+    hipFree(A->tile_cnt);
     delete A;
+    return BIS_OK;
+}
+
+// debugging / tuning aid: device addresses of the CRS arrays
+BIS_API bis_status bis_mat_debug_ptrs(const bis_mat *A, void **row_ptr, void **col, void **val) {
+    if (!A) return BIS_ERR_INVALID;
+    if (row_ptr) *row_ptr = A->row_ptr;
+    if (col) *col = A->col;
+    if (val) *val = A->val;
     return BIS_OK;
 }
 

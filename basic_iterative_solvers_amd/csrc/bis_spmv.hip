@@ -36,7 +36,7 @@ __device__ __forceinline__ V stream_load(const V *p) {
 // T threads; U = 4-non-zero vectors staged per lane before the first use
 // (all loads of a stage are in flight together); NT = nontemporal val/col
 // loads (streamed once: keep them from evicting x out of L2).
-template <typename RP, int T, int U, bool NT, bool FUSE_DOT, int DBG = 0>
+template <typename RP, int T, int U, bool NT, bool FUSE_DOT>
 __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
@@ -71,19 +71,10 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
         for (int u = 0; u < U; ++u) {
             const int64_t k = k0 + (int64_t)u * 4 * T;
             if (k < e) {
-                if (DBG == 1) { // tuning probe: no gather at all
-                    va[u].x *= (double)c[u].x; va[u].y *= (double)c[u].y;
-                    vb[u].x *= (double)c[u].z; vb[u].y *= (double)c[u].w;
-                } else if (DBG == 2) { // tuning probe: coalesced pseudo-gather
-                    const v2d xa = *reinterpret_cast<const v2d *>(x + ((k + c[u].x * 0) & 0xFFFFF));
-                    const v2d xb = *reinterpret_cast<const v2d *>(x + ((k + 2 + c[u].z * 0) & 0xFFFFF));
-                    va[u] *= xa; vb[u] *= xb;
-                } else {
                 va[u].x *= x[c[u].x];
                 va[u].y *= x[c[u].y];
                 vb[u].x *= x[c[u].z];
                 vb[u].y *= x[c[u].w];
-                }
             }
         }
 #pragma unroll
@@ -115,6 +106,7 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     }
 }
 
+
 // Fallback for rows longer than the LDS budget: one wave per row.
 template <typename RP>
 __global__ __launch_bounds__(256) void spmv_wave_per_row_kernel(
@@ -130,6 +122,164 @@ __global__ __launch_bounds__(256) void spmv_wave_per_row_kernel(
             acc = fma(val[k], x[col[k]], acc);
         acc = wave_sum(acc);
         if (lane == 0) y[r] = acc;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// x-window variant.  Analysis (once per matrix): for every row block, the
+// sorted list of the 16-column tiles of x its non-zeros reference (<= 128
+// tiles) and, per non-zero, a 16-bit offset into that window.  The SpMV then
+//   phase 0  copies the block's x tiles into LDS with coalesced loads (each x
+//            entry once per block instead of one L1 gather per non-zero),
+//   phase 1  streams val (8 B) + offset (2 B) -- 10 B per non-zero instead of
+//            CRS's 12 -- and takes x from LDS,
+//   phase 2  sums rows from LDS as before.
+// Products, their order and the row sums are those of the CRS kernel; the CRS
+// arrays stay authoritative (download, split, triangular solves use them).
+// A matrix with a block touching more than 64 tiles keeps the gather kernel.
+// ---------------------------------------------------------------------------
+constexpr int kHash = 512;
+
+template <typename RP>
+__global__ __launch_bounds__(256) void window_build_kernel(
+    const int32_t *__restrict__ col, const int64_t *__restrict__ blk_nnz, int n_blocks,
+    int64_t loc_base, uint16_t *__restrict__ loc, int32_t *__restrict__ tiles,
+    int32_t *__restrict__ tile_cnt, int *__restrict__ status /* [0]=overflow flag, [1]=max tiles */) {
+    __shared__ int htab[kHash];
+    __shared__ int list[kWinMaxTiles], sorted[kWinMaxTiles];
+    __shared__ int cnt, overflow;
+    const int b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const int64_t s = blk_nnz[b], e = blk_nnz[b + 1];
+    for (int i = threadIdx.x; i < kHash; i += 256) htab[i] = -1;
+    if (threadIdx.x == 0) { cnt = 0; overflow = 0; }
+    __syncthreads();
+    for (int64_t k = s + threadIdx.x; k < e; k += 256) {
+        const int tile = col[k] / kWinTile;
+        unsigned h = ((unsigned)tile * 2654435761u) >> 23; // 9 bits -> kHash
+        for (int probe = 0; probe < kHash; ++probe) {
+            const int old = atomicCAS(&htab[h], -1, tile);
+            if (old == tile) break;
+            if (old == -1) {
+                const int slot = atomicAdd(&cnt, 1);
+                if (slot < kWinMaxTiles) list[slot] = tile; else overflow = 1;
+                break;
+            }
+            h = (h + 1) & (kHash - 1);
+            if (probe == kHash - 1) overflow = 1;
+        }
+    }
+    __syncthreads();
+    if (overflow) {
+        if (threadIdx.x == 0) { tile_cnt[b] = -1; atomicExch(&status[0], 1); }
+        return;
+    }
+    const int n = cnt;
+    if ((int)threadIdx.x < n) { // rank sort of distinct values
+        const int v = list[threadIdx.x];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += list[j] < v;
+        sorted[rank] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n) tiles[(size_t)b * kWinMaxTiles + threadIdx.x] = sorted[threadIdx.x];
+    if (threadIdx.x == 0) { tile_cnt[b] = n; atomicMax(&status[1], n); }
+    for (int64_t k = s + threadIdx.x; k < e; k += 256) {
+        const int c = col[k], tile = c / kWinTile;
+        int lo = 0, hi = n - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted[mid] < tile) lo = mid + 1; else hi = mid; }
+        loc[k - loc_base] = (uint16_t)(lo * kWinTile + (c - tile * kWinTile));
+    }
+}
+
+typedef unsigned short v4us __attribute__((ext_vector_type(4)));
+
+template <typename RP, int T, int U, bool FUSE_DOT>
+__global__ __launch_bounds__(T) void spmv_window_kernel(
+    const RP *__restrict__ row_ptr, const uint16_t *__restrict__ loc, int64_t loc_base,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const int32_t *__restrict__ blk_row, const int64_t *__restrict__ blk_nnz,
+    const int32_t *__restrict__ tiles, const int32_t *__restrict__ tile_cnt, int64_t n_cols,
+    int xw_doubles, int n_blocks, int n_blocks_pad8, const double *__restrict__ w,
+    double *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *xw = smem;                // [xw_doubles]  x window
+    double *prod = smem + xw_doubles; // products
+    const int b = xcd_remap(blockIdx.x, n_blocks_pad8);
+    if (b >= n_blocks) return;
+    const int r0 = blk_row[b], r1 = blk_row[b + 1];
+    const int64_t s = blk_nnz[b], e = blk_nnz[b + 1];
+    const int64_t s4 = s & ~(int64_t)3;
+    const int nt = tile_cnt[b];
+    const int my_r = r0 + (int)threadIdx.x;
+    RP rp_a = 0, rp_z = 0;
+    if (my_r < r1) { rp_a = row_ptr[my_r]; rp_z = row_ptr[my_r + 1]; }
+
+    // issue the first stage of the val/offset stream before the window fill
+    v4us lc[U];
+    v2d va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t k = s4 + 4 * (int64_t)threadIdx.x + (int64_t)u * 4 * T;
+        if (k < e) {
+            lc[u] = *reinterpret_cast<const v4us *>(loc + (k - loc_base));
+            va[u] = *reinterpret_cast<const v2d *>(val + k);
+            vb[u] = *reinterpret_cast<const v2d *>(val + k + 2);
+        }
+    }
+    // phase 0: x tiles -> LDS (coalesced 128 B per tile)
+    for (int i = threadIdx.x; i < nt * kWinTile; i += T) {
+        const int64_t c = (int64_t)tiles[(size_t)b * kWinMaxTiles + (i >> kWinTileLog)] * kWinTile + (i & (kWinTile - 1));
+        xw[i] = c < n_cols ? x[c] : 0.0;
+    }
+    __syncthreads();
+    // phase 1
+    for (int64_t k0 = s4 + 4 * (int64_t)threadIdx.x; k0 < e; k0 += 4 * T * U) {
+        if (k0 != s4 + 4 * (int64_t)threadIdx.x) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = k0 + (int64_t)u * 4 * T;
+                if (k < e) {
+                    lc[u] = *reinterpret_cast<const v4us *>(loc + (k - loc_base));
+                    va[u] = *reinterpret_cast<const v2d *>(val + k);
+                    vb[u] = *reinterpret_cast<const v2d *>(val + k + 2);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = k0 + (int64_t)u * 4 * T;
+            if (k < e) {
+                // elements before s / after e in the 4-aligned vector belong to a
+                // neighbouring block (or the padding): their offsets are not for
+                // this window -- clamp, the products are never read
+                const int lim = nt * kWinTile - 1;
+                va[u].x *= xw[min((int)lc[u].x, lim)];
+                va[u].y *= xw[min((int)lc[u].y, lim)];
+                vb[u].x *= xw[min((int)lc[u].z, lim)];
+                vb[u].y *= xw[min((int)lc[u].w, lim)];
+                v2d *dst = reinterpret_cast<v2d *>(prod + (k - s4));
+                dst[0] = va[u];
+                dst[1] = vb[u];
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: one lane per row, left-to-right sum in CRS order
+    double dot_acc = 0.0;
+    for (int r = my_r; r < r1; r += T) {
+        if (r != my_r) { rp_a = row_ptr[r]; rp_z = row_ptr[r + 1]; }
+        const int a = (int)((int64_t)rp_a - s4), z = (int)((int64_t)rp_z - s4);
+        double acc = 0.0;
+        for (int j = a; j < z; ++j) acc += prod[j];
+        y[r] = acc;
+        if (FUSE_DOT) dot_acc = fma(acc, w[r], dot_acc);
+    }
+    if (FUSE_DOT) {
+        __shared__ double red[T / 64];
+        const double t = block_sum<T>(dot_acc, red);
+        if (threadIdx.x == 0) partials[b] = t;
     }
 }
 
@@ -161,12 +311,6 @@ bool launch_by_id(int id, const SpmvArgs &a) {
     case 21: launch_variant<RP, 256, 2, true>(a); return true;
     case 40: launch_variant<RP, 256, 4, false>(a); return true;
     case 41: launch_variant<RP, 256, 4, true>(a); return true;
-    case 9001: hipLaunchKernelGGL((spmv_rowblock_kernel<RP, 256, 4, false, false, 1>), dim3(a.nb8), dim3(256),
-                           a.lds_bytes, a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y,
-                           a.blk_row, a.blk_nnz, a.nb, a.nb8, a.w, a.partials); return true;
-    case 9002: hipLaunchKernelGGL((spmv_rowblock_kernel<RP, 256, 4, false, false, 2>), dim3(a.nb8), dim3(256),
-                           a.lds_bytes, a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y,
-                           a.blk_row, a.blk_nnz, a.nb, a.nb8, a.w, a.partials); return true;
     case 1040: launch_variant<RP, 128, 4, false>(a); return true;
     case 1020: launch_variant<RP, 128, 2, false>(a); return true;
     case 2040: launch_variant<RP, 64, 4, false>(a); return true;
@@ -181,16 +325,52 @@ bool launch_by_id(int id, const SpmvArgs &a) {
     }
 }
 
-int spmv_variant() {
-    static int v = -1;
-    if (v < 0) {
-        v = 40;
-        if (const char *e = getenv("BIS_SPMV_VARIANT")) v = atoi(e);
-    }
-    return v;
-}
+int spmv_variant() { return bis_opts().spmv_variant < 0 ? 40 : bis_opts().spmv_variant; }
 
 } // namespace
+
+// The x-window variant is opt-in (spmv_window=1): measured 1.20-1.33 ms against
+// 1.00-1.12 ms for the gather kernel on HPCG-256 (profiles/).
+int spmv_window_mode() { return bis_opts().spmv_window < 0 ? 0 : bis_opts().spmv_window; }
+
+bis_status bis_spmv_build_window(bis_ctx *ctx, bis_mat *A) {
+    A->win_ok = false;
+    if (!spmv_window_mode() || A->nnz == 0 || A->n_rows == 0) return BIS_OK;
+    if ((int64_t)A->chunk_nnz + A->max_row_nnz + 8 > 6144) return BIS_OK; // LDS: products + 16 KiB window <= 64 KiB
+    const int nb = A->n_blocks;
+    int64_t ends[2];
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[0], A->blk_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[1], A->blk_nnz + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    A->loc_base = ends[0] & ~(int64_t)3;
+    const size_t n_loc = (size_t)(ends[1] - A->loc_base) + 16;
+    hipFree(A->loc); hipFree(A->tiles); hipFree(A->tile_cnt);
+    A->loc = nullptr; A->tiles = nullptr; A->tile_cnt = nullptr;
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->loc, sizeof(uint16_t) * n_loc));
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->tiles, sizeof(int32_t) * (size_t)nb * kWinMaxTiles));
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->tile_cnt, sizeof(int32_t) * (size_t)nb));
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(A->loc, 0, sizeof(uint16_t) * n_loc, ctx->stream));
+    int *status = (int *)ctx->counters + 40;
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream));
+    if (A->rp64)
+        hipLaunchKernelGGL(window_build_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, A->col,
+                           A->blk_nnz, nb, A->loc_base, A->loc, A->tiles, A->tile_cnt, status);
+    else
+        hipLaunchKernelGGL(window_build_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, A->col,
+                           A->blk_nnz, nb, A->loc_base, A->loc, A->tiles, A->tile_cnt, status);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    int h[2] = {0, 0};
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[0]) { // some block touches too many tiles: keep the gather kernel, drop the structure
+        hipFree(A->loc); hipFree(A->tiles); hipFree(A->tile_cnt);
+        A->loc = nullptr; A->tiles = nullptr; A->tile_cnt = nullptr;
+        return BIS_OK;
+    }
+    A->max_tiles = h[1];
+    A->win_ok = true;
+    return BIS_OK;
+}
 
 // internal: y = A x, optionally partials[b] = sum_{r in block b} y[r]*w[r]
 // (n_partials returns the number of partials written; 0 if not fused).
@@ -218,6 +398,23 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     if (w && partials_off + (size_t)nb > ctx->partials_cap) {
         ctx->err = "bis_spmv: partials buffer too small (internal)";
         return BIS_ERR_INVALID;
+    }
+    if (A->win_ok && spmv_window_mode()) {
+        const int xw_doubles = ((A->max_tiles * kWinTile) + 1) & ~1;
+        const size_t lds_win = lds_bytes + sizeof(double) * (size_t)xw_doubles;
+        bis_prof_begin(ctx);
+#define BIS_WIN_LAUNCH(RP, FUSE)                                                                   \
+    hipLaunchKernelGGL((spmv_window_kernel<RP, 256, 2, FUSE>), dim3(nb8), dim3(256), lds_win,      \
+                       ctx->stream, (const RP *)A->row_ptr, A->loc, A->loc_base, A->val, x, y,     \
+                       A->blk_row, A->blk_nnz, A->tiles, A->tile_cnt, A->n_cols, xw_doubles, nb,   \
+                       nb8, w, ctx->partials + partials_off)
+        if (A->rp64) { if (w) BIS_WIN_LAUNCH(int64_t, true); else BIS_WIN_LAUNCH(int64_t, false); }
+        else { if (w) BIS_WIN_LAUNCH(int32_t, true); else BIS_WIN_LAUNCH(int32_t, false); }
+#undef BIS_WIN_LAUNCH
+        bis_prof_end(ctx);
+        BIS_HIP_CHECK(ctx, hipGetLastError());
+        if (w && n_partials) *n_partials = nb;
+        return BIS_OK;
     }
     SpmvArgs a{A->row_ptr, A->col, A->val, x, y, A->blk_row, A->blk_nnz, nb, nb8, w,
                ctx->partials + partials_off, lds_bytes,

@@ -217,8 +217,7 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     // 1024; Anderson-256 4.5 ms at 256, 13.5 ms at 1024).
     int64_t want = (4 * p->max_level_width + kTrsvT - 1) / kTrsvT + 1;
     want = std::min<int64_t>(want, ctx->n_cus);
-    static const int env_grid = getenv("BIS_TRSV_GRID") ? atoi(getenv("BIS_TRSV_GRID")) : 0;
-    if (env_grid > 0) want = env_grid;
+    if (bis_opts().trsv_grid > 0) want = bis_opts().trsv_grid;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_tickets, want),
                                                                  (int64_t)ctx->n_cus * 4));
     if (T->rp64)

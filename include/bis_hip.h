@@ -79,6 +79,9 @@ BIS_API void *bis_ctx_stream(bis_ctx *ctx);
 /* "gfx950", CU count, HBM bytes -- for logs and the bench JSON. */
 BIS_API bis_status bis_device_info(bis_ctx *ctx, char *arch, size_t arch_len,
                                    int *n_cus, int64_t *hbm_bytes);
+/* Tuning knobs, process-wide: "spmv_variant", "spmv_window", "spmv_chunk",
+ * "trsv_grid" (-1 = default).  Matrices created afterwards pick them up. */
+BIS_API bis_status bis_set_option(const char *name, int value);
 /* number of exported kernel-level symbols, for the load test */
 BIS_API int bis_abi_version(void);
 
@@ -109,6 +112,9 @@ BIS_API bis_status bis_mat_create64(bis_ctx *ctx, int64_t n_rows,
 BIS_API bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A);
 BIS_API bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows,
                                 int64_t *n_cols, int64_t *nnz);
+/* device addresses of the CRS arrays (tuning / zero-copy interop) */
+BIS_API bis_status bis_mat_debug_ptrs(const bis_mat *A, void **row_ptr,
+                                      void **col, void **val);
 /* copy the device CRS back (tests: bit-exact CRS checks); any pointer may be
  * NULL.  row_ptr is returned as int64. */
 BIS_API bis_status bis_mat_download(bis_ctx *ctx, const bis_mat *A,
