@@ -162,6 +162,8 @@ bis_status bis_ensure_partials(bis_ctx *ctx, size_t n);
 bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x,
                            double *y, const double *w, int *n_partials,
                            size_t partials_off = 0);
+bis_status bis_spmv_trsv_level(bis_ctx *ctx, const bis_mat *T, const double *x, double *y,
+                               const double *b, const double *D);
 // rows [ra,rb) of A as a matrix sharing A's arrays (y must be offset by ra)
 bis_status bis_mat_row_view(bis_ctx *ctx, const bis_mat *A, int64_t ra,
                             int64_t rb, bis_mat **out);

@@ -27,19 +27,23 @@ __global__ void max_row_kernel(const RP *row_ptr, int64_t n_rows, int *out_max) 
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out_max, m);
 }
 
-// blk_row[k] = first row r with row_ptr[r] >= k*chunk  (k = 0..n_blocks-1);
-// blk_row[n_blocks] = n_rows.
+// Row blocks balanced on weight(r) = (row_ptr[r] - row_ptr[0]) + r, i.e. non-zeros
+// plus rows before row r: blk_row[k] = first row with weight >= k*chunk, so a
+// block holds at most ~chunk non-zeros AND at most chunk rows (long runs of
+// empty rows -- strict triangles of colour-sorted matrices -- still spread over
+// many workgroups).  blk_row[n_blocks] = n_rows.
 template <typename RP>
 __global__ void row_blocks_kernel(const RP *row_ptr, int64_t n_rows, int n_blocks,
                                   int64_t chunk, int32_t *blk_row, int64_t *blk_nnz) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > n_blocks) return;
     if (k == n_blocks) { blk_row[k] = (int32_t)n_rows; blk_nnz[k] = (int64_t)row_ptr[n_rows]; return; }
-    const int64_t target = (int64_t)row_ptr[0] + (int64_t)k * chunk; // views: row_ptr[0] != 0
+    const int64_t base = (int64_t)row_ptr[0]; // views: row_ptr[0] != 0
+    const int64_t target = (int64_t)k * chunk;
     int64_t lo = 0, hi = n_rows; // answer in [0, n_rows]
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
+        if ((int64_t)row_ptr[mid] - base + mid >= target) hi = mid; else lo = mid + 1;
     }
     blk_row[k] = (int32_t)lo;
     blk_nnz[k] = (int64_t)row_ptr[lo];
@@ -261,7 +265,7 @@ bis_status finalize_t(bis_ctx *ctx, bis_mat *A) {
     A->max_row_nnz = h_max;
     int chunk = bis_opts().spmv_chunk > 0 ? std::max(256, bis_opts().spmv_chunk) : 2048;
     A->chunk_nnz = chunk;
-    int64_t nb = (A->nnz + chunk - 1) / chunk;
+    int64_t nb = (A->nnz + A->n_rows + chunk - 1) / chunk;
     if (nb < 1) nb = 1;
     A->n_blocks = (int)nb;
     if (A->blk_row) hipFree(A->blk_row);

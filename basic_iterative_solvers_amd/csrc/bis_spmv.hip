@@ -36,12 +36,18 @@ __device__ __forceinline__ V stream_load(const V *p) {
 // T threads; U = 4-non-zero vectors staged per lane before the first use
 // (all loads of a stage are in flight together); NT = nontemporal val/col
 // loads (streamed once: keep them from evicting x out of L2).
-template <typename RP, int T, int U, bool NT, bool FUSE_DOT>
+// MODE 0: y = A x.  MODE 1: also partials[b] = sum y[r]*w[r] (CG's (Ap,p)).
+// MODE 2: triangular-sweep epilogue for one dependency level given as a row
+// range: y[r] = (w[r] - (A x)[r]) / dinv_or_d[r], i.e. x_level = (b - T x)/D
+// (kernels.hpp:70,102); y may be the same array as x -- rows of one level do
+// not reference each other.
+template <typename RP, int T, int U, bool NT, int MODE>
 __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ val, const double *x, double *y,
     const int32_t *__restrict__ blk_row, const int64_t *__restrict__ blk_nnz, int n_blocks,
-    int n_blocks_pad8, const double *__restrict__ w, double *__restrict__ partials) {
+    int n_blocks_pad8, const double *w, double *partials) {
+    constexpr bool FUSE_DOT = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) double prod[];
     const int b = xcd_remap(blockIdx.x, n_blocks_pad8);
     if (b >= n_blocks) return;
@@ -96,7 +102,8 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
         const int a = (int)((int64_t)rp_a - s4), z = (int)((int64_t)rp_z - s4);
         double acc = 0.0;
         for (int j = a; j < z; ++j) acc += prod[j];
-        y[r] = acc;
+        if (MODE == 2) y[r] = (w[r] - acc) / partials[r];
+        else y[r] = acc;
         if (FUSE_DOT) dot_acc = fma(acc, w[r], dot_acc);
     }
     if (FUSE_DOT) {
@@ -286,19 +293,19 @@ __global__ __launch_bounds__(T) void spmv_window_kernel(
 struct SpmvArgs {
     const void *row_ptr; const int32_t *col; const double *val; const double *x; double *y;
     const int32_t *blk_row; const int64_t *blk_nnz; int nb, nb8; const double *w; double *partials;
-    size_t lds_bytes; hipStream_t stream;
+    size_t lds_bytes; hipStream_t stream; int mode;
 };
 
 template <typename RP, int T, int U, bool NT>
 void launch_variant(const SpmvArgs &a) {
-    if (a.w)
-        hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, NT, true>), dim3(a.nb8), dim3(T),
-                           a.lds_bytes, a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y,
-                           a.blk_row, a.blk_nnz, a.nb, a.nb8, a.w, a.partials);
-    else
-        hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, NT, false>), dim3(a.nb8), dim3(T),
-                           a.lds_bytes, a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y,
-                           a.blk_row, a.blk_nnz, a.nb, a.nb8, a.w, a.partials);
+#define BIS_LV(MODE)                                                                              \
+    hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, NT, MODE>), dim3(a.nb8), dim3(T), a.lds_bytes, \
+                       a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y, a.blk_row, a.blk_nnz, \
+                       a.nb, a.nb8, a.w, a.partials)
+    if (a.mode == 2) BIS_LV(2);
+    else if (a.mode == 1) BIS_LV(1);
+    else BIS_LV(0);
+#undef BIS_LV
 }
 
 // variant id = T/256-1 (0,1,3) * 100 + U * 10 + NT      (tuning knob BIS_SPMV_VARIANT)
@@ -418,7 +425,7 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     }
     SpmvArgs a{A->row_ptr, A->col, A->val, x, y, A->blk_row, A->blk_nnz, nb, nb8, w,
                ctx->partials + partials_off, lds_bytes,
-               ctx->stream};
+               ctx->stream, w ? 1 : 0};
     bis_prof_begin(ctx);
     const bool ok = A->rp64 ? launch_by_id<int64_t>(spmv_variant(), a)
                             : launch_by_id<int32_t>(spmv_variant(), a);
@@ -426,6 +433,23 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     if (!ok) { ctx->err = "bis_spmv: unknown BIS_SPMV_VARIANT"; return BIS_ERR_INVALID; }
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (w && n_partials) *n_partials = nb;
+    return BIS_OK;
+}
+
+// internal: one triangular-sweep level on the row range a view T covers:
+// y[r] = (b[r] - (T x)[r]) / D[r]  (y, b, D already offset to the view's first row)
+bis_status bis_spmv_trsv_level(bis_ctx *ctx, const bis_mat *T, const double *x, double *y,
+                               const double *b, const double *D) {
+    if (T->n_rows == 0) return BIS_OK;
+    const int64_t lds_doubles = (int64_t)T->chunk_nnz + T->max_row_nnz + 8;
+    const size_t lds_bytes = sizeof(double) * (size_t)lds_doubles;
+    if (lds_bytes > 64 * 1024) { ctx->err = "sptrsv level: row too long for the streaming kernel"; return BIS_ERR_UNSUPPORTED; }
+    const int nb = T->n_blocks, nb8 = (nb + 7) & ~7;
+    SpmvArgs a{T->row_ptr, T->col, T->val, x, y, T->blk_row, T->blk_nnz, nb, nb8, b,
+               const_cast<double *>(D), lds_bytes, ctx->stream, 2};
+    const bool ok = T->rp64 ? launch_by_id<int64_t>(40, a) : launch_by_id<int32_t>(40, a);
+    if (!ok) return BIS_ERR_INVALID;
+    BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
 }
 

@@ -36,6 +36,10 @@ struct bis_trsv_plan {
     int n_levels = 0;
     int64_t n = 0;
     int64_t max_level_width = 0;
+    std::vector<int64_t> level_ptr; // host: positions of the level boundaries in perm
+    // few-level orderings whose levels are contiguous row ranges: one row view per level
+    std::vector<bis_mat *> level_views;
+    std::vector<int64_t> level_row0;
 };
 
 void bis_trsv_plan_destroy(bis_trsv_plan *p) {
@@ -43,6 +47,10 @@ void bis_trsv_plan_destroy(bis_trsv_plan *p) {
     hipFree(p->perm);
     hipFree(p->xs);
     hipFree(p->ticket);
+    for (bis_mat *v : p->level_views) { // row views: only their block tables are theirs
+        hipFree(v->blk_row); hipFree(v->blk_nnz); hipFree(v->loc); hipFree(v->tiles); hipFree(v->tile_cnt);
+        delete v;
+    }
     delete p;
 }
 
@@ -117,10 +125,34 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
     }
 }
 
+
+// Few, wide levels (multi-colour orderings: 2-16 levels of 10^5..10^7 rows):
+// one plain launch per level, one lane per row, no flags and no polling -- the
+// kernel boundary is the hand-off.  x may alias b.
+template <typename RP>
+__global__ __launch_bounds__(256) void trsv_level_kernel(const RP *__restrict__ row_ptr,
+                                                         const int32_t *__restrict__ col,
+                                                         const double *__restrict__ val,
+                                                         const int32_t *__restrict__ perm,
+                                                         int64_t begin, int64_t end,
+                                                         const double *__restrict__ D, const double *b,
+                                                         double *x) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = begin + (int64_t)blockIdx.x * 256 + threadIdx.x; i < end; i += stride) {
+        const int r = perm[i];
+        double acc = 0.0;
+        for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k)
+            acc = fma(val[k], x[col[k]], acc);
+        x[r] = (b[r] - acc) / D[r];
+    }
+}
+constexpr int kFewLevels = 64;
+
 // Host analysis: levels and the level-sorted permutation.
 template <typename RP>
 void build_perm(const RP *rp, const int32_t *col, int64_t n, bool backward,
-                std::vector<int32_t> &perm, int &n_levels, int64_t &max_width) {
+                std::vector<int32_t> &perm, int &n_levels, int64_t &max_width,
+                std::vector<int64_t> &level_ptr) {
     std::vector<int32_t> level(n, 0);
     int maxl = 0;
     if (!backward) {
@@ -143,6 +175,7 @@ void build_perm(const RP *rp, const int32_t *col, int64_t n, bool backward,
     for (int64_t r = 0; r < n; ++r) start[level[r] + 1]++;
     for (int l = 0; l < n_levels; ++l) start[l + 1] += start[l];
     perm.resize(n);
+    level_ptr.assign(start.begin(), start.end());
     max_width = 0;
     for (int l = 0; l < n_levels; ++l) max_width = std::max<int64_t>(max_width, start[l + 1] - start[l]);
     for (int64_t r = 0; r < n; ++r) perm[start[level[r]]++] = (int32_t)r;
@@ -177,7 +210,7 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
     std::vector<int32_t> perm;
     bis_trsv_plan *p = new bis_trsv_plan;
     p->n = n;
-    build_perm(rp.data(), col.data(), n, backward, perm, p->n_levels, p->max_level_width);
+    build_perm(rp.data(), col.data(), n, backward, perm, p->n_levels, p->max_level_width, p->level_ptr);
     hipError_t e = hipMalloc(&p->perm, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1));
     if (e == hipSuccess) e = hipMalloc(&p->xs, sizeof(double) * (size_t)std::max<int64_t>(n, 1));
     if (e == hipSuccess) e = hipMalloc(&p->ticket, sizeof(unsigned) * 4);
@@ -189,6 +222,24 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
         ctx->err = std::string("sptrsv plan: ") + hipGetErrorString(e);
         bis_trsv_plan_destroy(p);
         return BIS_ERR_HIP;
+    }
+    // Few levels, each a contiguous ascending row range (a colour-sorted matrix):
+    // sweep each level with the streaming SpMV kernel + triangular epilogue.
+    if (p->n_levels <= kFewLevels && n > 0) {
+        bool contiguous = true;
+        for (int l = 0; l < p->n_levels && contiguous; ++l)
+            for (int64_t i = p->level_ptr[l]; i + 1 < p->level_ptr[l + 1]; ++i)
+                if (perm[i + 1] != perm[i] + 1) { contiguous = false; break; }
+        if (contiguous && (int64_t)T->chunk_nnz + T->max_row_nnz + 8 <= 8192) {
+            for (int l = 0; l < p->n_levels; ++l) {
+                const int64_t r0 = perm[p->level_ptr[l]];
+                bis_mat *v = nullptr;
+                st = bis_mat_row_view(ctx, T, r0, r0 + (p->level_ptr[l + 1] - p->level_ptr[l]), &v);
+                if (st != BIS_OK) { for (auto *m : p->level_views) bis_mat_destroy(ctx, m); p->level_views.clear(); break; }
+                p->level_views.push_back(v);
+                p->level_row0.push_back(r0);
+            }
+        }
     }
     slot = p;
     *out = p;
@@ -205,11 +256,33 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     bis_trsv_plan *p = nullptr;
     bis_status st = get_plan(ctx, T, backward, &p);
     if (st != BIS_OK) return st;
+    if (!p->level_views.empty()) {
+        for (int l = 0; l < p->n_levels; ++l) {
+            const int64_t r0 = p->level_row0[l];
+            st = bis_spmv_trsv_level(ctx, p->level_views[l], x, x + r0, b + r0, D + r0);
+            if (st != BIS_OK) return st;
+        }
+        return BIS_OK;
+    }
+    if (p->n_levels <= kFewLevels) {
+        for (int l = 0; l < p->n_levels; ++l) {
+            const int64_t lo = p->level_ptr[l], hi = p->level_ptr[l + 1];
+            const int grid = (int)std::min<int64_t>((hi - lo + 255) / 256, (int64_t)ctx->n_cus * 32);
+            if (T->rp64)
+                hipLaunchKernelGGL(trsv_level_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream,
+                                   (const int64_t *)T->row_ptr, T->col, T->val, p->perm, lo, hi, D, b, x);
+            else
+                hipLaunchKernelGGL(trsv_level_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream,
+                                   (const int32_t *)T->row_ptr, T->col, T->val, p->perm, lo, hi, D, b, x);
+        }
+        BIS_HIP_CHECK(ctx, hipGetLastError());
+        return BIS_OK;
+    }
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,
                        (unsigned long long *)p->xs, n);
     BIS_HIP_CHECK(ctx, hipMemsetAsync(p->ticket, 0, sizeof(unsigned), ctx->stream));
-    // persistent grid: resident by construction (<= 4 workgroups of 256 per CU)
+    // persistent grid: resident by construction (<= 8 workgroups of 256 per CU, 51 VGPRs)
     const int64_t n_tickets = (n + kTrsvT - 1) / kTrsvT;
     // Only ~one level is runnable at a time: keep a few of the widest levels
     // resident, at most one workgroup per CU -- idle pollers slow the hand-offs
@@ -219,7 +292,7 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     want = std::min<int64_t>(want, ctx->n_cus);
     if (bis_opts().trsv_grid > 0) want = bis_opts().trsv_grid;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_tickets, want),
-                                                                 (int64_t)ctx->n_cus * 4));
+                                                                 (int64_t)ctx->n_cus * 8));
     if (T->rp64)
         hipLaunchKernelGGL(sptrsv_syncfree_kernel<int64_t>, dim3(grid), dim3(kTrsvT), 0, ctx->stream,
                            (const int64_t *)T->row_ptr, T->col, T->val, p->perm, n, D, b, x,

@@ -76,6 +76,8 @@ struct Args {
     int restart_length = 10;
     bool num_scale = false;
     bool unfused = false; // -unfused: CG runs the reference's kernel-by-kernel schedule
+    std::string perm_mode = "none"; // -perm mc: multi-colour reordering (SMAX PERM_MODE role)
+    std::string dump_perm;          // -dump-perm FILE: write perm[new]=old
     int device = 0;
 };
 

@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include "solver.hpp"
 #include "utilities/LU_factors.hpp"
+#include "utilities/permute.hpp"
 
 inline void download_to_host(MatrixCRS *A) { // device-generated matrix -> host arrays (setup only)
     if (A->row_ptr) return;
@@ -74,6 +75,31 @@ inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::u
         // copied the unscaled x_0 into the iterate; x_0 is not read again
         elemwise_mult_vectors(solver->x_0, solver->A_D_scale, solver->x_0, N);
         elemwise_mult_vectors(solver->b, solver->A_D_scale, solver->b, N);
+    }
+
+    if (cli_args->perm_mode == "mc") { // the SMAX permute_mat step (preprocessing.hpp:58-62)
+        download_to_host(solver->A.get());
+        std::vector<int> perm, inv_perm;
+        int n_colours = 0;
+        multicolour_permutation(solver->A.get(), perm, inv_perm, n_colours);
+        auto B = std::make_unique<MatrixCRS>();
+        permute_matrix(solver->A.get(), perm, inv_perm, B.get());
+        B->upload();
+        solver->A = std::move(B);
+        // x_0 is the constant INIT_X_VAL (invariant under P); b is constant too
+        // unless -scale has rescaled it: permute it through the host (setup only)
+        if (solver->num_scale) {
+            const int N = solver->A->n_rows;
+            std::vector<double> hb(N), pb(N);
+            to_host(hb.data(), solver->b, N);
+            for (int i = 0; i < N; ++i) pb[i] = hb[perm[i]];
+            to_device(solver->b, pb.data(), N);
+        }
+        if (!cli_args->dump_perm.empty()) write_permutation(cli_args->dump_perm, perm);
+        std::cout << "multi-colour reordering: " << n_colours << " colours" << std::endl;
+    } else if (cli_args->perm_mode != "none") {
+        fprintf(stderr, "ERROR: unknown -perm mode (available: mc)\n");
+        exit(EXIT_FAILURE);
     }
 
     solver->L = std::make_unique<MatrixCRS>();

@@ -4,7 +4,8 @@
 // may be a generator string instead of a file (the reference does the same
 // with SCAMAC strings when built with -DUSE_SCAMAC, main.cpp:48-54):
 //     hpcg:N | hpcg:NX,NY,NZ | anderson:L[,shift=S][,W=w][,t=t][,seed=k]
-// and `-unfused` / `-dev K` select the kernel-by-kernel CG and the device.
+// and `-unfused` / `-dev K` select the kernel-by-kernel CG and the device;
+// `-perm mc` applies the multi-colour reordering of utilities/permute.hpp.
 #pragma once
 
 #include "../common.hpp"
@@ -57,6 +58,8 @@ inline void parse_cli(Args *a, int argc, char *argv[]) {
         } else if (arg == "-scale" && i + 1 < argc) a->num_scale = (bool)atoi(argv[++i]);
         else if (arg == "-rl" && i + 1 < argc) a->restart_length = atoi(argv[++i]);
         else if (arg == "-unfused") a->unfused = true;
+        else if (arg == "-perm" && i + 1 < argc) a->perm_mode = argv[++i];
+        else if (arg == "-dump-perm" && i + 1 < argc) a->dump_perm = argv[++i];
         else if (arg == "-dev" && i + 1 < argc) a->device = atoi(argv[++i]);
         else std::cout << "ERROR: assign_cli_inputs: Arguement \"" << arg << "\" not recongnized." << std::endl;
     }

@@ -310,3 +310,29 @@ def test_full_size_hpcg256_properties(ctx):
     ctx.spmv(dA, du, yu); ctx.spmv(dA, dv, yv)
     a, b2 = ctx.dot(yu, dv), ctx.dot(du, yv)
     assert abs(a - b2) <= 1e-12 * max(abs(a), 1.0) * 10
+
+
+def test_sptrsv_few_level_path_bit_exact(ctx, oracle):
+    """Orderings with few, wide dependency levels (multi-colour) take the
+    per-level streaming path (SpMV kernel + triangular epilogue: products are
+    rounded before the left-to-right row sum, so <= 1e-13 instead of bit-exact);
+    x aliases b."""
+    rng = np.random.default_rng(3)
+    n = 20000
+    # red-black-like: rows [n/2, n) depend only on rows [0, n/2)
+    lens = np.concatenate([np.zeros(n // 2, dtype=np.int64), rng.integers(1, 9, n - n // 2)])
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    col = rng.integers(0, n // 2, rp[-1]).astype(np.int32)
+    Ls = CRS(n, rp, col, rng.uniform(-1, 1, rp[-1]))
+    D, b = rng.uniform(1, 2, n), rng.uniform(-1, 1, n)
+    dLs, dD = ctx.matrix(Ls), ctx.upload(D)
+    x = ctx.upload(b)
+    ctx.sptrsv(dLs, x, dD, x)
+    assert relerr(x.to_host(), oracle.sptrsv(Ls, D, b.copy())) <= KTOL
+    # transposed structure -> backward solve
+    Us = CRS(n, np.concatenate([rp[n // 2:] - rp[n // 2], np.full(n // 2, rp[-1])]),
+             (col + n // 2).astype(np.int32), Ls.val)
+    dUs = ctx.matrix(Us)
+    x2 = ctx.alloc(n)
+    ctx.bsptrsv(dUs, x2, dD, ctx.upload(b))
+    assert relerr(x2.to_host(), oracle.sptrsv(Us, D, b.copy(), backward=True)) <= KTOL

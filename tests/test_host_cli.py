@@ -84,3 +84,37 @@ def test_cli_errors():
     assert out.returncode != 0 and "Unable to open file" in out.stderr
     out = subprocess.run([BIN, "hpcg:4"], capture_output=True, text=True)
     assert out.returncode != 0 and "Not enough arguments" in out.stdout
+
+
+@pytest.mark.parametrize("name,solver,pc", [("hpcg8", "gm", "gs"), ("hpcg8", "cg", "sgs"),
+                                            ("anderson8_shift9", "bi", "ilu0"),
+                                            ("anderson8_shift9", "gs", "none"),
+                                            ("FDM-2d-16", "cg", "sgs")])
+def test_cli_multicolour_reordering_vs_oracle_on_permuted_matrix(tmp_path, oracle, name, solver, pc):
+    """-perm mc changes the Gauss-Seidel / ILU iteration; its parity target is
+    the reference algorithm (oracle) run on the same permuted matrix P A P^T
+    (the protocol of the reference's SMAX path, smax_helpers.hpp:44-80)."""
+    from helpers import crs_of, load_golden
+    from oracle.pyoracle import CRS
+    permfile = str(tmp_path / "perm.txt")
+    kw = {"restart_len": 50} if solver == "gm" else {}
+    r = run_cli(name, solver, pc, kw, extra=["-perm", "mc", "-dump-perm", permfile])
+    perm = np.loadtxt(permfile, dtype=np.int64)
+    A = crs_of(load_golden(name), "A")
+    n = A.n_rows
+    assert sorted(perm) == list(range(n))
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    lens = np.diff(A.row_ptr)[perm]
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    col = np.concatenate([inv[A.col[A.row_ptr[o]:A.row_ptr[o + 1]]] for o in perm]).astype(np.int32)
+    val = np.concatenate([A.val[A.row_ptr[o]:A.row_ptr[o + 1]] for o in perm])
+    B = CRS(n, rp, col, val)
+    # colouring property: no row couples to a row of its own colour block -> few levels
+    m = re.search(r"multi-colour reordering: (\d+) colours", r["stdout"])
+    assert m and int(m.group(1)) <= 16
+    o = oracle.solve(B, solver, pc, ilu_real=True, **kw)
+    e = dict(hist=[float(v) for v in o["hist"]], iters=o["iters"], converged=o["converged"])
+    check_history(r, e, solver)
+    if solver != "bi":
+        assert abs(r["iters"] - o["iters"]) <= 1
