@@ -72,22 +72,18 @@ def torch_comm_ops(td, torch, n_ranks, rank, group=None):
         try:
             with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
                 torch.cuda.current_stream().synchronize()
-                reqs, so, ro = [], 0, 0
-                keep = []
+                ops, so, ro = [], 0, 0
                 for p in range(n):
                     sc, rc = int(send_counts[p]), int(recv_counts[p])
                     if sc:
-                        t = wrap(sendbuf + 8 * so, sc)
-                        keep.append(t)
-                        reqs.append(td.isend(t, p, group=group))
+                        ops.append(td.P2POp(td.isend, wrap(sendbuf + 8 * so, sc), p, group))
                     if rc:
-                        t = wrap(recvbuf + 8 * ro, rc)
-                        keep.append(t)
-                        reqs.append(td.irecv(t, p, group=group))
+                        ops.append(td.P2POp(td.irecv, wrap(recvbuf + 8 * ro, rc), p, group))
                     so += sc
                     ro += rc
-                for r in reqs:
-                    r.wait()
+                if ops:  # batched: safe for both gloo and nccl process groups
+                    for r in td.batch_isend_irecv(ops):
+                        r.wait()
                 torch.cuda.current_stream().synchronize()
             return 0
         except Exception as ex:  # noqa

@@ -131,7 +131,7 @@ def main():
         dA = ctx.matrix(A_loc)
         d = Dist(ctx, dA, rank, world, row_starts)
         route_send_lists(d, td)
-        if world == 1 and kind == "hpcg":
+        if (world == 1 and kind == "hpcg") or os.environ.get("BIS_TEST_FORCE_RCCL") == "1":
             setup_rccl(ctx, d, td)  # exercises the RCCL binding (self all-reduce)
         else:
             d.set_comm(torch_comm_ops(td, torch, world, rank))
