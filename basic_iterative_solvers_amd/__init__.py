@@ -129,6 +129,15 @@ class Context:
                                                  C.c_void_p(D.ptr), C.c_void_p(Dinv.ptr)))
         return Mat(self, hl), Mat(self, hu), D, Dinv
 
+    def ilu0(self, A, pivot_tol=1e-8, pivot_repl=1e-4):
+        n = A.n_rows
+        L_D, U_D = self.alloc(n), self.alloc(n)
+        hl, hu = C.c_void_p(), C.c_void_p()
+        self.check(self.lib.bis_mat_ilu0(self.h, A.h, C.c_double(pivot_tol), C.c_double(pivot_repl),
+                                         C.byref(hl), C.byref(hu), C.c_void_p(L_D.ptr),
+                                         C.c_void_p(U_D.ptr)))
+        return Mat(self, hl), L_D, Mat(self, hu), U_D
+
     # ---- kernels (kernels.hpp names) ---------------------------------------
     def spmv(self, A, x, y):
         self.check(self.lib.bis_spmv(self.h, A.h, C.c_void_p(x.ptr), C.c_void_p(y.ptr)))

@@ -219,7 +219,7 @@ static bis_status cg_create_common(bis_ctx *ctx, bis_dist *dist, const bis_mat *
     cg->x = x;
     cg->n = dist ? bis_dist_n_local(dist) : A->n_rows;
     const int64_t n_ext = dist ? bis_dist_n_ext(dist) : cg->n; // p is the SpMV input: needs the halo tail
-    cg->hist_cap = 4096;
+    cg->hist_cap = 1 << 16;
     bis_status st = bis_vec_alloc(ctx, n_ext, &cg->p);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->n, &cg->r);
     if (st == BIS_OK && A_D) st = bis_vec_alloc(ctx, cg->n, &cg->z);

@@ -174,3 +174,8 @@ bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols,
 bis_status bis_mat_finalize(bis_ctx *ctx, bis_mat *A);
 bis_status bis_spmv_build_window(bis_ctx *ctx, bis_mat *A);
 void bis_trsv_plan_destroy(bis_trsv_plan *p);
+bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
+                                     bis_mat **U_strict, double *D, double *D_inv, bool check_diag);
+// dependency levels of a strict-lower matrix: host level boundaries + device row list
+bis_status bis_trsv_level_sets(bis_ctx *ctx, const bis_mat *T_lower, const std::vector<int64_t> **level_ptr,
+                               const int32_t **perm_dev);

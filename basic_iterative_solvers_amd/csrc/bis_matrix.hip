@@ -508,8 +508,22 @@ bis_status bis_mat_gen_anderson(bis_ctx *ctx, int64_t L, double t, double W, dou
     return BIS_OK;
 }
 
+} // extern "C"
+
+bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
+                                     bis_mat **U_strict, double *D, double *D_inv, bool check_diag);
+
+extern "C" {
+
 bis_status bis_mat_split_strict(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
                                 bis_mat **U_strict, double *D, double *D_inv) {
+    return bis_mat_split_strict_impl(ctx, A, L_strict, U_strict, D, D_inv, true);
+}
+
+} // extern "C"
+
+bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
+                                     bis_mat **U_strict, double *D, double *D_inv, bool check_diag) {
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, A && L_strict && U_strict, "bis_mat_split_strict: bad arguments");
     BIS_REQUIRE(ctx, A->n_rows == A->n_cols, "bis_mat_split_strict: square local matrix required");
@@ -558,7 +572,7 @@ bis_status bis_mat_split_strict(bis_ctx *ctx, const bis_mat *A, bis_mat **L_stri
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h_status, status, 8, hipMemcpyDeviceToHost, ctx->stream));
     BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(blk);
-    if (h_status != ~0ull) {
+    if (check_diag && h_status != ~0ull) {
         const long long row = (long long)(h_status >> 1) - 1;
         const bool missing = h_status & 1ull;
         char msg[128];
@@ -577,5 +591,3 @@ bis_status bis_mat_split_strict(bis_ctx *ctx, const bis_mat *A, bis_mat **L_stri
     *U_strict = Um;
     return BIS_OK;
 }
-
-} // extern "C"

@@ -307,6 +307,16 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
 
 } // namespace
 
+bis_status bis_trsv_level_sets(bis_ctx *ctx, const bis_mat *T_lower, const std::vector<int64_t> **level_ptr,
+                               const int32_t **perm_dev) {
+    bis_trsv_plan *p = nullptr;
+    bis_status st = get_plan(ctx, T_lower, false, &p);
+    if (st != BIS_OK) return st;
+    *level_ptr = &p->level_ptr;
+    *perm_dev = p->perm;
+    return BIS_OK;
+}
+
 extern "C" {
 
 bis_status bis_sptrsv(bis_ctx *ctx, const bis_mat *L_strict, double *x, const double *D,

@@ -28,32 +28,34 @@ inline void scale_mat(MatrixCRS *A, const double *s) { // preprocessing.hpp:15-2
 // factor_LU, utilities/LU_factors.hpp:900-934
 inline void factor_LU(Solver *s) {
     const int N = s->A->n_rows;
-    const bool ilu = s->preconditioner == PrecondType::ILU0;
-    if (ilu) download_to_host(s->A.get());
     if (!s->A->row_ptr) {
         // device-resident input: split + diagonal on the device
         bis_mat *Ls = nullptr, *Us = nullptr;
         bis::check(bis_mat_split_strict(bis::ctx(), s->A->dev, &Ls, &Us, s->A_D, s->A_D_inv), "bis_mat_split_strict");
         s->L_strict->adopt(Ls);
         s->U_strict->adopt(Us);
-        return;
+    } else {
+        split_LU(s->A.get(), s->L.get(), s->L_strict.get(), s->U.get(), s->U_strict.get());
+        std::vector<double> D(N, 1.0), Dinv(N, 0.0);
+        peel_diag_crs(s->L.get(), D.data(), Dinv.data());
+        peel_diag_crs(s->U.get(), D.data(), Dinv.data());
+        to_device(s->A_D, D.data(), N);
+        to_device(s->A_D_inv, Dinv.data(), N);
+        s->L_strict->upload();
+        s->U_strict->upload();
     }
-    split_LU(s->A.get(), s->L.get(), s->L_strict.get(), s->U.get(), s->U_strict.get());
-    std::vector<double> D(N, 1.0), Dinv(N, 0.0);
-    peel_diag_crs(s->L.get(), D.data(), Dinv.data());
-    peel_diag_crs(s->U.get(), D.data(), Dinv.data());
-    to_device(s->A_D, D.data(), N);
-    to_device(s->A_D_inv, Dinv.data(), N);
-    if (ilu) {
-        // the serial ILU(0) of the reference (factor_ILU0_old); its wired-in
-        // factor_ILU0_new needs the SMAX library (defect 2)
-        std::vector<double> LD(N, 1.0), UD(N, 1.0);
-        factor_ILU0(s->A.get(), s->L_strict.get(), LD.data(), s->U_strict.get(), UD.data());
-        to_device(s->L_D, LD.data(), N);
-        to_device(s->U_D, UD.data(), N);
+    if (s->preconditioner == PrecondType::ILU0) {
+        // The reference's wired-in factor_ILU0_new needs the SMAX library (SURVEY.md
+        // section 5, defect 2); this is its serial factor_ILU0_old arithmetic,
+        // level-scheduled on the device.  Overwrites L_strict/U_strict, L_D, U_D.
+        bis_mat *Ls = nullptr, *Us = nullptr;
+        bis::check(bis_mat_ilu0(bis::ctx(), s->A->dev, ILU0_PIVOT_TOLERANCE, ILU0_PIVOT_REPLACEMENT, &Ls, &Us,
+                                s->L_D, s->U_D), "bis_mat_ilu0");
+        s->L_strict->free_host();
+        s->U_strict->free_host();
+        s->L_strict->adopt(Ls);
+        s->U_strict->adopt(Us);
     }
-    s->L_strict->upload();
-    s->U_strict->upload();
 }
 
 inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::unique_ptr<MatrixCRS> &A) {

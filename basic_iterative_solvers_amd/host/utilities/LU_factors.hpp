@@ -1,7 +1,8 @@
 // LU_factors.hpp -- host-side setup (run once): A -> L, L_strict, U, U_strict,
-// diagonal extraction and serial ILU(0), following the reference's
+// and diagonal extraction, following the reference's
 // utilities/LU_factors.hpp (split_LU :122-309, peel_diag_crs :827-869,
-// extract_scale :880-898, factor_ILU0_old :320-539, factor_LU :900-934).
+// extract_scale :880-898, factor_LU :900-934); ILU(0) itself runs on the device
+// (bis_mat_ilu0).
 // Outputs are bit-identical CRS arrays; the strict parts are uploaded to the
 // device where the triangular solves run.
 #pragma once
@@ -67,45 +68,4 @@ inline void extract_scale(MatrixCRS *A, double *D_scale) {
                 if (std::abs(A->val[j]) < 1e-16) SanityChecker::zero_diag(r);
                 D_scale[r] = 1.0 / std::sqrt(std::abs(A->val[j]));
             }
-}
-
-// Serial ILU(0) restricted to A's pattern (IKJ, ascending dependencies).
-// L_strict / U_strict must already hold A's strict parts' sizes (split_LU);
-// they are overwritten with the factors (ascending columns), L_D = 1, U_D = u_ii.
-inline void factor_ILU0(const MatrixCRS *A, MatrixCRS *L_strict, double *L_D, MatrixCRS *U_strict,
-                        double *U_D) {
-    const int n = A->n_rows;
-    std::vector<double> w(n, 0.0);
-    std::vector<int> idx;
-    int lp = 0, up = 0;
-    L_strict->row_ptr[0] = 0;
-    U_strict->row_ptr[0] = 0;
-    for (int i = 0; i < n; ++i) {
-        idx.clear();
-        for (int p = A->row_ptr[i]; p < A->row_ptr[i + 1]; ++p) { w[A->col[p]] = A->val[p]; idx.push_back(A->col[p]); }
-        std::sort(idx.begin(), idx.end());
-        for (int k : idx) {
-            if (k >= i) break;
-            const double pivot = U_D[k];
-            if (std::abs(pivot) < 1e-16) continue;
-            const double factor = w[k] / pivot;
-            w[k] = factor;
-            for (int p = U_strict->row_ptr[k]; p < U_strict->row_ptr[k + 1]; ++p) {
-                const int j = U_strict->col[p];
-                if (w[j] != 0.0) w[j] -= factor * U_strict->val[p];
-            }
-        }
-        double u_diag = 0.0;
-        for (int j : idx) {
-            if (j < i) { L_strict->col[lp] = j; L_strict->val[lp++] = w[j]; }
-            else if (j == i) u_diag = w[j];
-            else { U_strict->col[up] = j; U_strict->val[up++] = w[j]; }
-        }
-        if (std::abs(u_diag) < ILU0_PIVOT_TOLERANCE) u_diag = (u_diag >= 0 ? 1.0 : -1.0) * ILU0_PIVOT_REPLACEMENT;
-        U_D[i] = u_diag;
-        L_D[i] = 1.0;
-        L_strict->row_ptr[i + 1] = lp;
-        U_strict->row_ptr[i + 1] = up;
-        for (int j : idx) w[j] = 0.0;
-    }
 }

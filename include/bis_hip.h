@@ -145,6 +145,16 @@ BIS_API bis_status bis_mat_split_strict(bis_ctx *ctx, const bis_mat *A,
                                         bis_mat **L_strict, bis_mat **U_strict,
                                         double *D, double *D_inv);
 
+/* ILU(0) on the device: the arithmetic of the
+ * reference's serial factor_ILU0_old (utilities/LU_factors.hpp:320-539),
+ * scheduled by the dependency levels of A's strict lower triangle (its
+ * level-parallel factor_ILU0_new, :541-768, needs SMAX).  Outputs the strict
+ * factors with ascending columns, L_D = 1 and U_D = diag(U); the reference's
+ * pivot guard uses ILU0_PIVOT_TOLERANCE / ILU0_PIVOT_REPLACEMENT. */
+BIS_API bis_status bis_mat_ilu0(bis_ctx *ctx, const bis_mat *A, double pivot_tol,
+                                double pivot_repl, bis_mat **L_strict,
+                                bis_mat **U_strict, double *L_D, double *U_D);
+
 /* ---- the operator surface (kernels.hpp) ------------------------------------ */
 /* spmv / native_spmv, kernels.hpp:22-52: y = A x. */
 BIS_API bis_status bis_spmv(bis_ctx *ctx, const bis_mat *A, const double *x,

@@ -336,3 +336,32 @@ def test_sptrsv_few_level_path_bit_exact(ctx, oracle):
     x2 = ctx.alloc(n)
     ctx.bsptrsv(dUs, x2, dD, ctx.upload(b))
     assert relerr(x2.to_host(), oracle.sptrsv(Us, D, b.copy(), backward=True)) <= KTOL
+
+
+@pytest.mark.parametrize("name", GOLDEN_MATS)
+def test_device_ilu0_vs_reference_factors(ctx, name):
+    """bis_mat_ilu0 (level-parallel on the device) vs the reference's serial
+    factor_ILU0_old: same pattern (ascending columns), values <= 1e-13."""
+    g = load_golden(name)
+    dA = ctx.matrix(crs_of(g, "A"))
+    dLs, L_D, dUs, U_D = ctx.ilu0(dA)
+    rp, col, val = dLs.download()
+    assert np.array_equal(rp, g["iluLs_rp"]) and np.array_equal(col, g["iluLs_col"])
+    assert relerr(val, g["iluLs_val"]) <= KTOL
+    rp, col, val = dUs.download()
+    assert np.array_equal(rp, g["iluUs_rp"]) and np.array_equal(col, g["iluUs_col"])
+    assert relerr(val, g["iluUs_val"]) <= KTOL
+    assert relerr(U_D.to_host(), g["iluUD"]) <= KTOL
+    assert np.array_equal(L_D.to_host(), g["iluLD"])
+
+
+def test_device_ilu0_medium_vs_oracle(ctx, oracle):
+    A = oracle.gen_hpcg(20)
+    Ls, L_D, Us, U_D = oracle.factor_ilu0(A)
+    dLs, dL_D, dUs, dU_D = ctx.ilu0(ctx.gen_hpcg(20))
+    rp, col, val = dUs.download()
+    assert np.array_equal(rp, Us.row_ptr) and np.array_equal(col, Us.col)
+    assert relerr(val, Us.val) <= KTOL
+    rp, col, val = dLs.download()
+    assert np.array_equal(col, Ls.col) and relerr(val, Ls.val) <= KTOL
+    assert relerr(dU_D.to_host(), U_D) <= KTOL
