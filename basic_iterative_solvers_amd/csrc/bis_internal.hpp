@@ -6,12 +6,22 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "bis_hip.h"
 
 struct bis_trsv_plan;
+
+struct bis_named_kernel {
+    int type = 0;
+    const bis_mat *A = nullptr;
+    double *B = nullptr, *C = nullptr;
+    int64_t size_B = 0, size_C = 0;
+    const double *D = nullptr;
+    bool upper = false;
+};
 
 struct bis_ctx {
     int device = 0;
@@ -29,6 +39,8 @@ struct bis_ctx {
     double *scalars_dev = nullptr; // [64]
     double *scalars_host = nullptr; // pinned [64]
     unsigned *counters = nullptr; // [64] tickets / arrival counters (zeroed)
+
+    std::map<std::string, bis_named_kernel> kernels; // named-kernel registry (SMAX protocol)
 
     // profiling
     bool profile = false;

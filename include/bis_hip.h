@@ -235,6 +235,36 @@ BIS_API bis_status bis_apply_preconditioner(
     const double *L_D, const double *U_D, double *output, double *input,
     double *tmp, double *work, int outer_iters, int inner_iters);
 
+/* ---- named kernels: the reference's plugin protocol --------------------------
+ * The reference's accelerator seam (SMAX) registers each kernel once under a
+ * name with persistent operands, runs it by name, and rebinds operands after
+ * the solver's pointer swaps: utilities/smax_helpers.hpp:7-42
+ * (register_kernel / register_A / register_B / register_C /
+ * set_mat_upper_triang), kernels.hpp:48,82,113 (kernel(name)->run(0, offset,
+ * 0)), jacobi.hpp:93 / kernels.hpp:329 (swap_operands), cg.hpp:136-152
+ * (args->x->val = ...).  Same protocol here.  SPMV: C = A * B.  SPTRSV: solve
+ * (D + A) B = C with A strictly triangular (the reference hands SMAX a
+ * triangle with the diagonal inside; here D is a separate vector, as in the
+ * native path, registered with bis_kernel_register_D). */
+enum { BIS_KERNEL_SPMV = 0, BIS_KERNEL_SPTRSV = 1 };
+BIS_API bis_status bis_register_kernel(bis_ctx *ctx, const char *name, int type);
+BIS_API bis_status bis_kernel_register_A(bis_ctx *ctx, const char *name,
+                                         const bis_mat *A);
+BIS_API bis_status bis_kernel_register_B(bis_ctx *ctx, const char *name,
+                                         int64_t size, double *vec);
+BIS_API bis_status bis_kernel_register_C(bis_ctx *ctx, const char *name,
+                                         int64_t size, double *vec);
+BIS_API bis_status bis_kernel_register_D(bis_ctx *ctx, const char *name,
+                                         const double *diag);
+BIS_API bis_status bis_kernel_set_mat_upper_triang(bis_ctx *ctx,
+                                                   const char *name, int flag);
+/* offsets in elements, as in run(A_offset, B_offset, C_offset); A_offset must
+ * be 0 (the reference never passes anything else). */
+BIS_API bis_status bis_kernel_run(bis_ctx *ctx, const char *name,
+                                  int64_t A_offset, int64_t B_offset,
+                                  int64_t C_offset);
+BIS_API bis_status bis_kernel_swap_operands(bis_ctx *ctx, const char *name);
+
 /* ---- fused CG schedule (cg.hpp:6-54 + :162-166, same arithmetic, fewer
  * passes; SURVEY.md section 8d "fused lower bound") -------------------------- */
 typedef struct bis_cg bis_cg;

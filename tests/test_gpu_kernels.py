@@ -365,3 +365,78 @@ def test_device_ilu0_medium_vs_oracle(ctx, oracle):
     rp, col, val = dLs.download()
     assert np.array_equal(col, Ls.col) and relerr(val, Ls.val) <= KTOL
     assert relerr(dU_D.to_host(), U_D) <= KTOL
+
+
+def test_named_kernel_protocol(ctx, oracle):
+    """The reference's plugin protocol (smax_helpers.hpp:7-42, kernels.hpp:48,
+    cg.hpp:136-152, jacobi.hpp:93): register, run by name with an operand
+    offset (gmres.hpp:168-169), swap_operands, rebind."""
+    import ctypes as C
+    lib = ctx.lib
+    A = oracle.gen_hpcg(6)
+    n = A.n_rows
+    dA = ctx.matrix(A)
+    rng = np.random.default_rng(2)
+    V = rng.uniform(-1, 1, 3 * n)          # 3 basis vectors, like GMRES' V
+    dV, dw = ctx.upload(V), ctx.alloc(n)
+    name = b"w_j <- A*v_j"
+    ctx.check(lib.bis_register_kernel(ctx.h, name, 0))
+    ctx.check(lib.bis_kernel_register_A(ctx.h, name, dA.h))
+    ctx.check(lib.bis_kernel_register_B(ctx.h, name, C.c_int64(3 * n), C.c_void_p(dV.ptr)))
+    ctx.check(lib.bis_kernel_register_C(ctx.h, name, C.c_int64(n), C.c_void_p(dw.ptr)))
+    for j in range(3):
+        ctx.check(lib.bis_kernel_run(ctx.h, name, C.c_int64(0), C.c_int64(j * n), C.c_int64(0)))
+        assert relerr(dw.to_host(), oracle.spmv(A, V[j * n:(j + 1) * n])) <= KTOL
+    assert lib.bis_kernel_run(ctx.h, name, C.c_int64(0), C.c_int64(3 * n), C.c_int64(0)) != 0  # out of range
+    assert lib.bis_kernel_run(ctx.h, b"no such kernel", C.c_int64(0), C.c_int64(0), C.c_int64(0)) != 0
+    # Jacobi-style ping-pong: x_new <- A x_old, then swap_operands
+    x0, x1 = ctx.upload(V[:n]), ctx.alloc(n)
+    ctx.check(lib.bis_register_kernel(ctx.h, b"x_new <- A*x_old", 0))
+    ctx.check(lib.bis_kernel_register_A(ctx.h, b"x_new <- A*x_old", dA.h))
+    ctx.check(lib.bis_kernel_register_B(ctx.h, b"x_new <- A*x_old", C.c_int64(n), C.c_void_p(x0.ptr)))
+    ctx.check(lib.bis_kernel_register_C(ctx.h, b"x_new <- A*x_old", C.c_int64(n), C.c_void_p(x1.ptr)))
+    ctx.check(lib.bis_kernel_run(ctx.h, b"x_new <- A*x_old", C.c_int64(0), C.c_int64(0), C.c_int64(0)))
+    ctx.check(lib.bis_kernel_swap_operands(ctx.h, b"x_new <- A*x_old"))
+    ctx.check(lib.bis_kernel_run(ctx.h, b"x_new <- A*x_old", C.c_int64(0), C.c_int64(0), C.c_int64(0)))
+    assert relerr(x0.to_host(), oracle.spmv(A, oracle.spmv(A, V[:n]))) <= KTOL
+    # triangular solves by name, upper flag
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    dLs, dUs, dD = ctx.matrix(Ls), ctx.matrix(Us), ctx.upload(D)
+    b = rng.uniform(-1, 1, n)
+    db, dx = ctx.upload(b), ctx.alloc(n)
+    for nm, M, up, ref in ((b"solve L", dLs, 0, oracle.sptrsv(Ls, D, b)),
+                           (b"solve U", dUs, 1, oracle.sptrsv(Us, D, b, backward=True))):
+        ctx.check(lib.bis_register_kernel(ctx.h, nm, 1))
+        ctx.check(lib.bis_kernel_register_A(ctx.h, nm, M.h))
+        ctx.check(lib.bis_kernel_register_B(ctx.h, nm, C.c_int64(n), C.c_void_p(dx.ptr)))
+        ctx.check(lib.bis_kernel_register_C(ctx.h, nm, C.c_int64(n), C.c_void_p(db.ptr)))
+        ctx.check(lib.bis_kernel_register_D(ctx.h, nm, C.c_void_p(dD.ptr)))
+        ctx.check(lib.bis_kernel_set_mat_upper_triang(ctx.h, nm, up))
+        ctx.check(lib.bis_kernel_run(ctx.h, nm, C.c_int64(0), C.c_int64(0), C.c_int64(0)))
+        assert np.array_equal(dx.to_host(), ref)
+
+
+def test_full_size_anderson256_properties(ctx):
+    """BASELINE configs 2-4 size (Anderson 256^3, 16.7M rows): symmetry of the
+    operator, and the triangular solves inverted exactly by a product:
+    (D + L) sptrsv(L, D, b) == b and (D + U) bsptrsv(U, D, b) == b."""
+    L1 = 256
+    N = L1 ** 3
+    dA = ctx.gen_anderson(L1, shift=9.0)
+    assert dA.nnz == 7 * N
+    rng = np.random.default_rng(4)
+    u, v = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N)
+    du, dv, yu, yv = ctx.upload(u), ctx.upload(v), ctx.alloc(N), ctx.alloc(N)
+    ctx.spmv(dA, du, yu); ctx.spmv(dA, dv, yv)
+    a, b2 = ctx.dot(yu, dv), ctx.dot(du, yv)
+    assert abs(a - b2) <= 1e-12 * max(abs(a), abs(b2), 1.0)
+    dLs, dUs, dD, dDinv = ctx.split_strict(dA)
+    x, t = ctx.alloc(N), ctx.alloc(N)
+    for solve, T in ((ctx.sptrsv, dLs), (ctx.bsptrsv, dUs)):
+        solve(T, x, dD, du)
+        ctx.spmv(T, x, t)                       # t = T x
+        ctx.elemwise_mult_vectors(yu, dD, x)    # yu = D x
+        ctx.sum_vectors(t, t, yu)               # (D + T) x
+        ctx.subtract_vectors(t, t, du)
+        assert ctx.euclidean_vec_norm(t) <= 1e-13 * np.sqrt(N) * 20
