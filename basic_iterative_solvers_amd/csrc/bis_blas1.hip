@@ -179,6 +179,8 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_SPMV_VARIANT")) v.spmv_variant = atoi(e);
         if (const char *e = getenv("BIS_SPMV_WINDOW")) v.spmv_window = atoi(e);
         if (const char *e = getenv("BIS_SPMV_CHUNK")) v.spmv_chunk = atoi(e);
+        if (const char *e = getenv("BIS_SPMV_CHUNK_FUSED")) v.spmv_chunk_fused = atoi(e);
+        if (const char *e = getenv("BIS_SPMV_XCD_REMAP")) v.spmv_xcd_remap = atoi(e);
         if (const char *e = getenv("BIS_TRSV_GRID")) v.trsv_grid = atoi(e);
         return v;
     }();
@@ -194,6 +196,8 @@ bis_status bis_set_option(const char *name, int value) {
     if (!strcmp(name, "spmv_variant")) o.spmv_variant = value;
     else if (!strcmp(name, "spmv_window")) o.spmv_window = value;
     else if (!strcmp(name, "spmv_chunk")) o.spmv_chunk = value;
+    else if (!strcmp(name, "spmv_chunk_fused")) o.spmv_chunk_fused = value;
+    else if (!strcmp(name, "spmv_xcd_remap")) o.spmv_xcd_remap = value;
     else if (!strcmp(name, "trsv_grid")) o.trsv_grid = value;
     else return BIS_ERR_INVALID;
     return BIS_OK;

@@ -311,8 +311,8 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
     const int64_t n = cg->n;
     if (n == 0) return BIS_OK;
     const int g = grid_for(n);
-    const size_t nblk = cg->dist ? (size_t)bis_dist_total_blocks(cg->dist) : (size_t)cg->A->n_blocks;
-    bis_status st = bis_ensure_partials(ctx, std::max((size_t)2 * kMaxReduceBlocks, nblk));
+    const size_t nblk = cg->dist ? (size_t)bis_dist_total_blocks(cg->dist) : (size_t)cg->A->n_blocks_f;
+    bis_status st = bis_ensure_partials(ctx, std::max((size_t)2 * kMaxReduceBlocks, nblk * 16)); // <= 16 waves per row block
     if (st != BIS_OK) return st;
     for (int it = 0; it < n_iters; ++it) {
         int n_part = 0;

@@ -395,7 +395,7 @@ bis_status bis_dist_spmv_launch(bis_ctx *ctx, bis_dist *d, double *x_ext, double
     return BIS_OK;
 }
 
-int bis_dist_total_blocks(const bis_dist *d) { return d->lo->n_blocks + d->mid->n_blocks + d->hi->n_blocks; }
+int bis_dist_total_blocks(const bis_dist *d) { return d->lo->n_blocks_f + d->mid->n_blocks_f + d->hi->n_blocks_f; }
 int64_t bis_dist_n_local(const bis_dist *d) { return d->n_local; }
 int64_t bis_dist_n_ext(const bis_dist *d) { return d->n_local + d->n_halo; }
 const bis_mat *bis_dist_matrix(const bis_dist *d) { return d->A; }

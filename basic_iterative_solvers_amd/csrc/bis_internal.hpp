@@ -52,7 +52,9 @@ struct bis_ctx {
 struct bis_options {
     int spmv_variant = -1; // -1: default (40 = 256 threads, 4 staged vectors)
     int spmv_window = -1;  // -1: default (0: CRS gather kernel)
-    int spmv_chunk = -1;   // -1: default (2048 non-zeros per row block)
+    int spmv_chunk = -1;   // -1: default (1024 non-zeros + rows per row block)
+    int spmv_chunk_fused = -1; // -1: default (2048) for the SpMV with the fused dot epilogue
+    int spmv_xcd_remap = -1; // 1: each XCD sweeps its own slab of row blocks (default: blockIdx order)
     int trsv_grid = -1;    // -1: automatic
 };
 bis_options &bis_opts();
@@ -82,6 +84,11 @@ struct bis_mat {
     int max_tiles = 0;
     bool win_ok = false;
     int n_blocks = 0;
+    // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
+    int32_t *blkf_row = nullptr;
+    int64_t *blkf_nnz = nullptr;
+    int n_blocks_f = 0;
+    int chunk_f = 0;
     int chunk_nnz = 0;        // nnz budget per block used to build blk_row
     int max_row_nnz = 0;
     int64_t max_block_nnz = 0;

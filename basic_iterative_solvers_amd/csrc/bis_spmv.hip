@@ -11,9 +11,13 @@
 //   * after one barrier each lane owns a row and sums that row's products
 //     from LDS left to right (CRS storage order, like the reference's scalar
 //     loop), then writes y coalesced;
-//   * the blockIdx -> row-block map is XCD-aware: each XCD sweeps one
-//     contiguous slab of rows so the x planes a stencil row touches stay in
-//     that XCD's 4 MiB L2 (MI355X_MICROARCH.md, "Workgroup dispatch").
+//   * row blocks are taken in blockIdx order: the 8 XCDs then stream ONE
+//     advancing window of val/col together.  (An XCD-aware map that gives each
+//     XCD its own contiguous slab of rows -- so that a stencil's x planes stay
+//     in one L2 -- was measured 3-9 % SLOWER on HPCG-256, 1.122 vs 1.085 ms:
+//     eight far-apart HBM streams cost more than the x re-fetches they save,
+//     which the 256 MiB Infinity Cache absorbs.  Kept as option
+//     "spmv_xcd_remap".)
 //
 // Rows longer than the LDS budget fall back to a wave-per-row kernel.
 // An optional fused epilogue accumulates sum_r y[r]*w[r] (the (Ap,p) of
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     int n_blocks_pad8, const double *w, double *partials) {
     constexpr bool FUSE_DOT = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) double prod[];
-    const int b = xcd_remap(blockIdx.x, n_blocks_pad8);
+    const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8) : (int)blockIdx.x;
     if (b >= n_blocks) return;
     // one dependent level only: row range and nnz range come from the block
     // table; the row_ptr entries phase 2 needs are fetched now, under phase 1
@@ -106,106 +110,13 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
         else y[r] = acc;
         if (FUSE_DOT) dot_acc = fma(acc, w[r], dot_acc);
     }
-    if (FUSE_DOT) {
-        __shared__ double red[T / 64];
-        const double t = block_sum<T>(dot_acc, red);
-        if (threadIdx.x == 0) partials[b] = t;
+    if (FUSE_DOT) { // one partial per wave (no workgroup barrier): kSpmvWaves per row block
+        const double t = wave_sum(dot_acc);
+        if ((threadIdx.x & 63) == 0) partials[(size_t)b * (T / 64) + (threadIdx.x >> 6)] = t;
     }
 }
 
 
-
-// "row-major" variant: phase 1 only STAGES the block's val/col stream in LDS
-// (coalesced 16-byte loads, no gather); phase 2 gives each lane one row and
-// walks it left to right: acc = fma(val, x[col], acc) -- CRS order with fma,
-// bit-identical to the scalar reference loop.  Across the lanes of a wave the
-// j-th gather then reads x[col_j(row)] of 64 CONSECUTIVE rows: for stencil-like
-// matrices those addresses are consecutive, i.e. one coalesced 512-byte load
-// instead of a 64-way scatter through the texture-address path.
-// L lanes share a row (L = 1, 2, 4, 8 by mean row length): each takes a
-// contiguous 1/L of the row, the L partial sums are combined left to right.
-template <typename RP, int T, int U, int MODE, int L>
-__global__ __launch_bounds__(T) void spmv_rowmajor_kernel(
-    const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
-    const double *__restrict__ val, const double *x, double *y,
-    const int32_t *__restrict__ blk_row, const int64_t *__restrict__ blk_nnz, int n_blocks,
-    int n_blocks_pad8, const double *w, double *partials, int cap) {
-    constexpr bool FUSE_DOT = MODE == 1;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *lv = smem;                                   // [cap] values
-    int *lc = reinterpret_cast<int *>(smem + cap);       // [cap] columns
-    const int b = xcd_remap(blockIdx.x, n_blocks_pad8);
-    if (b >= n_blocks) return;
-    const int r0 = blk_row[b], r1 = blk_row[b + 1];
-    const int64_t s = blk_nnz[b], e = blk_nnz[b + 1];
-    const int64_t s4 = s & ~(int64_t)3;
-    const int sub = (int)threadIdx.x % L;
-    const int my_r = r0 + (int)threadIdx.x / L;
-    RP rp_a = 0, rp_z = 0;
-    if (my_r < r1) { rp_a = row_ptr[my_r]; rp_z = row_ptr[my_r + 1]; }
-    for (int64_t k0 = s4 + 4 * (int64_t)threadIdx.x; k0 < e; k0 += 4 * T * U) {
-        v4i c[U];
-        v2d va[U], vb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t k = k0 + (int64_t)u * 4 * T;
-            if (k < e) {
-                c[u] = *reinterpret_cast<const v4i *>(col + k);
-                va[u] = *reinterpret_cast<const v2d *>(val + k);
-                vb[u] = *reinterpret_cast<const v2d *>(val + k + 2);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t k = k0 + (int64_t)u * 4 * T;
-            if (k < e) {
-                *reinterpret_cast<v4i *>(lc + (k - s4)) = c[u];
-                v2d *dst = reinterpret_cast<v2d *>(lv + (k - s4));
-                dst[0] = va[u];
-                dst[1] = vb[u];
-            }
-        }
-    }
-    __syncthreads();
-    double dot_acc = 0.0;
-    // (r1 - r0) rounded up so that all L lanes of a row group stay in the loop together
-    for (int r = my_r; r < r1; r += T / L) { // the L lanes of a group share r
-        if (r != my_r) { rp_a = row_ptr[r]; rp_z = row_ptr[r + 1]; }
-        int a = (int)((int64_t)rp_a - s4), z = (int)((int64_t)rp_z - s4);
-        if (L > 1) { // this lane's contiguous share of the row
-            const int q = (z - a + L - 1) / L;
-            a = min(a + sub * q, z);
-            z = min(a + q, z);
-        }
-        double acc = 0.0;
-        int j = a;
-        for (; j + 4 <= z; j += 4) { // 4 gathers in flight, consumed in order
-            const int c0 = lc[j], c1 = lc[j + 1], c2 = lc[j + 2], c3 = lc[j + 3];
-            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-            acc = fma(lv[j], x0, acc);
-            acc = fma(lv[j + 1], x1, acc);
-            acc = fma(lv[j + 2], x2, acc);
-            acc = fma(lv[j + 3], x3, acc);
-        }
-        for (; j < z; ++j) acc = fma(lv[j], x[lc[j]], acc);
-        if (L > 1) { // combine the L shares left to right on the group's first lane
-            double tot = acc;
-#pragma unroll
-            for (int i = 1; i < L; ++i) tot += __shfl_down(acc, i, L);
-            acc = tot;
-        }
-        if (sub == 0) {
-            if (MODE == 2) y[r] = (w[r] - acc) / partials[r];
-            else y[r] = acc;
-            if (FUSE_DOT) dot_acc = fma(acc, w[r], dot_acc);
-        }
-    }
-    if (FUSE_DOT) {
-        __shared__ double red[T / 64];
-        const double t = block_sum<T>(dot_acc, red);
-        if (threadIdx.x == 0) partials[b] = t;
-    }
-}
 
 // Fallback for rows longer than the LDS budget: one wave per row.
 template <typename RP>
@@ -306,7 +217,7 @@ __global__ __launch_bounds__(T) void spmv_window_kernel(
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *xw = smem;                // [xw_doubles]  x window
     double *prod = smem + xw_doubles; // products
-    const int b = xcd_remap(blockIdx.x, n_blocks_pad8);
+    const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8) : (int)blockIdx.x;
     if (b >= n_blocks) return;
     const int r0 = blk_row[b], r1 = blk_row[b + 1];
     const int64_t s = blk_nnz[b], e = blk_nnz[b + 1];
@@ -376,17 +287,16 @@ __global__ __launch_bounds__(T) void spmv_window_kernel(
         y[r] = acc;
         if (FUSE_DOT) dot_acc = fma(acc, w[r], dot_acc);
     }
-    if (FUSE_DOT) {
-        __shared__ double red[T / 64];
-        const double t = block_sum<T>(dot_acc, red);
-        if (threadIdx.x == 0) partials[b] = t;
+    if (FUSE_DOT) { // one partial per wave (no workgroup barrier): kSpmvWaves per row block
+        const double t = wave_sum(dot_acc);
+        if ((threadIdx.x & 63) == 0) partials[(size_t)b * (T / 64) + (threadIdx.x >> 6)] = t;
     }
 }
 
 struct SpmvArgs {
     const void *row_ptr; const int32_t *col; const double *val; const double *x; double *y;
     const int32_t *blk_row; const int64_t *blk_nnz; int nb, nb8; const double *w; double *partials;
-    size_t lds_bytes; hipStream_t stream; int mode; int lanes_per_row = 1;
+    size_t lds_bytes; hipStream_t stream; int mode; int n_cus = 256; bool remap = false;
 };
 
 template <typename RP, int T, int U, bool NT>
@@ -394,7 +304,7 @@ void launch_variant(const SpmvArgs &a) {
 #define BIS_LV(MODE)                                                                              \
     hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, NT, MODE>), dim3(a.nb8), dim3(T), a.lds_bytes, \
                        a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y, a.blk_row, a.blk_nnz, \
-                       a.nb, a.nb8, a.w, a.partials)
+                       a.nb, a.remap ? a.nb8 : -1, a.w, a.partials)
     if (a.mode == 2) BIS_LV(2);
     else if (a.mode == 1) BIS_LV(1);
     else BIS_LV(0);
@@ -411,20 +321,6 @@ bool launch_by_id(int id, const SpmvArgs &a) {
     case 21: launch_variant<RP, 256, 2, true>(a); return true;
     case 40: launch_variant<RP, 256, 4, false>(a); return true;
     case 41: launch_variant<RP, 256, 4, true>(a); return true;
-    case 60: case 61: { // row-major variant: LDS holds val (8 B) + col (4 B) per non-zero
-        const int cap = (int)((a.lds_bytes / sizeof(double) + 1) & ~(size_t)1);
-        const size_t lds = (size_t)cap * 12;
-#define BIS_RM(MODE, LL)                                                                         \
-    hipLaunchKernelGGL((spmv_rowmajor_kernel<RP, 256, 4, MODE, LL>), dim3(a.nb8), dim3(256), lds, \
-                       a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y, a.blk_row,        \
-                       a.blk_nnz, a.nb, a.nb8, a.w, a.partials, cap)
-#define BIS_RML(LL) do { if (a.mode == 2) BIS_RM(2, LL); else if (a.mode == 1) BIS_RM(1, LL); else BIS_RM(0, LL); } while (0)
-        const int lanes = a.lanes_per_row;
-        if (lanes >= 8) BIS_RML(8); else if (lanes >= 4) BIS_RML(4); else if (lanes >= 2) BIS_RML(2); else BIS_RML(1);
-#undef BIS_RML
-#undef BIS_RM
-        return true;
-    }
     case 1040: launch_variant<RP, 128, 4, false>(a); return true;
     case 1020: launch_variant<RP, 128, 2, false>(a); return true;
     case 2040: launch_variant<RP, 64, 4, false>(a); return true;
@@ -439,21 +335,16 @@ bool launch_by_id(int id, const SpmvArgs &a) {
     }
 }
 
-// lanes sharing a row in the row-major variant, by mean row length
-int lanes_for(const bis_mat *A) {
-    const double avg = A->n_rows ? (double)A->nnz / (double)A->n_rows : 0.0;
-    return avg >= 48 ? 8 : avg >= 20 ? 4 : avg >= 10 ? 2 : 1;
-}
+// Default: 256 threads, up to 4 staged vectors per lane (variant 40).  Tuning
+// history (tools/spmv_ab.py, same arrays, interleaved rounds, HPCG-256):
+// chunk 1024 1.019 ms | 1280 1.026 | 1536 1.047 | 2048 1.084 | 4096 1.100;
+// 128-thread blocks 1.10; a lane-per-row "row-major" phase 2 (fma order) 1.23-1.30;
+// a persistent, software-pipelined grid 1.23-1.48; 64 consecutive non-zeros per
+// gather instruction (8/4-byte loads) 1.23; nontemporal val/col loads +10 %.
+// threads per workgroup of a variant id (the fused dot writes one partial per wave)
+int fused_threads(int id) { return id >= 2000 ? 64 : id >= 1000 ? 128 : id >= 300 ? 1024 : id >= 100 ? 512 : 256; }
 
-// Default kernel by matrix shape (measured, gpurun A/B in one process):
-//   short rows (mean < 10 nnz, e.g. the 7-point Anderson operator): the
-//   row-major variant, 0.318 vs 0.338 ms on Anderson-256;
-//   otherwise the product-staging variant (HPCG-256: 1.12 vs 1.23 ms).
-int spmv_variant(const bis_mat *A) {
-    if (bis_opts().spmv_variant >= 0) return bis_opts().spmv_variant;
-    const double avg = A->n_rows ? (double)A->nnz / (double)A->n_rows : 0.0;
-    return avg < 10.0 ? 60 : 40;
-}
+int spmv_variant(const bis_mat *) { return bis_opts().spmv_variant < 0 ? 40 : bis_opts().spmv_variant; }
 
 } // namespace
 
@@ -506,7 +397,8 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
                            const double *w, int *n_partials, size_t partials_off) {
     if (n_partials) *n_partials = 0;
     if (A->n_rows == 0) return BIS_OK;
-    const int64_t lds_doubles = (int64_t)A->chunk_nnz + A->max_row_nnz + 8;
+    const bool use_f = w != nullptr && !(A->win_ok && spmv_window_mode()); // fused epilogue: its own table
+    const int64_t lds_doubles = (int64_t)(use_f ? A->chunk_f : A->chunk_nnz) + A->max_row_nnz + 8;
     const size_t lds_bytes = sizeof(double) * (size_t)lds_doubles;
     if (lds_bytes > 64 * 1024) {
         if (w) { ctx->err = "bis_spmv: fused dot unsupported for very long rows"; return BIS_ERR_UNSUPPORTED; }
@@ -522,8 +414,8 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
         BIS_HIP_CHECK(ctx, hipGetLastError());
         return BIS_OK;
     }
-    const int nb = A->n_blocks, nb8 = (nb + 7) & ~7;
-    if (w && partials_off + (size_t)nb > ctx->partials_cap) {
+    const int nb = use_f ? A->n_blocks_f : A->n_blocks, nb8 = (nb + 7) & ~7;
+    if (w && partials_off + (size_t)nb * 4 > ctx->partials_cap) {
         ctx->err = "bis_spmv: partials buffer too small (internal)";
         return BIS_ERR_INVALID;
     }
@@ -535,26 +427,28 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     hipLaunchKernelGGL((spmv_window_kernel<RP, 256, 2, FUSE>), dim3(nb8), dim3(256), lds_win,      \
                        ctx->stream, (const RP *)A->row_ptr, A->loc, A->loc_base, A->val, x, y,     \
                        A->blk_row, A->blk_nnz, A->tiles, A->tile_cnt, A->n_cols, xw_doubles, nb,   \
-                       nb8, w, ctx->partials + partials_off)
+                       bis_opts().spmv_xcd_remap > 0 ? nb8 : -1, w, ctx->partials + partials_off)
         if (A->rp64) { if (w) BIS_WIN_LAUNCH(int64_t, true); else BIS_WIN_LAUNCH(int64_t, false); }
         else { if (w) BIS_WIN_LAUNCH(int32_t, true); else BIS_WIN_LAUNCH(int32_t, false); }
 #undef BIS_WIN_LAUNCH
         bis_prof_end(ctx);
         BIS_HIP_CHECK(ctx, hipGetLastError());
-        if (w && n_partials) *n_partials = nb;
+        if (w && n_partials) *n_partials = nb * 4; // 256-thread workgroups: 4 waves
         return BIS_OK;
     }
-    SpmvArgs a{A->row_ptr, A->col, A->val, x, y, A->blk_row, A->blk_nnz, nb, nb8, w,
+    SpmvArgs a{A->row_ptr, A->col, A->val, x, y, use_f ? A->blkf_row : A->blk_row,
+               use_f ? A->blkf_nnz : A->blk_nnz, nb, nb8, w,
                ctx->partials + partials_off, lds_bytes,
                ctx->stream, w ? 1 : 0};
-    a.lanes_per_row = lanes_for(A);
+    a.n_cus = ctx->n_cus;
+    a.remap = bis_opts().spmv_xcd_remap > 0;
     bis_prof_begin(ctx);
     const bool ok = A->rp64 ? launch_by_id<int64_t>(spmv_variant(A), a)
                             : launch_by_id<int32_t>(spmv_variant(A), a);
     bis_prof_end(ctx);
     if (!ok) { ctx->err = "bis_spmv: unknown BIS_SPMV_VARIANT"; return BIS_ERR_INVALID; }
     BIS_HIP_CHECK(ctx, hipGetLastError());
-    if (w && n_partials) *n_partials = nb;
+    if (w && n_partials) *n_partials = nb * (fused_threads(spmv_variant(A)) / 64);
     return BIS_OK;
 }
 
@@ -569,7 +463,8 @@ bis_status bis_spmv_trsv_level(bis_ctx *ctx, const bis_mat *T, const double *x, 
     const int nb = T->n_blocks, nb8 = (nb + 7) & ~7;
     SpmvArgs a{T->row_ptr, T->col, T->val, x, y, T->blk_row, T->blk_nnz, nb, nb8, b,
                const_cast<double *>(D), lds_bytes, ctx->stream, 2};
-    a.lanes_per_row = lanes_for(T);
+    a.n_cus = ctx->n_cus;
+    a.remap = bis_opts().spmv_xcd_remap > 0;
     const bool ok = T->rp64 ? launch_by_id<int64_t>(spmv_variant(T), a) : launch_by_id<int32_t>(spmv_variant(T), a);
     if (!ok) return BIS_ERR_INVALID;
     BIS_HIP_CHECK(ctx, hipGetLastError());

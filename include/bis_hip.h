@@ -112,6 +112,8 @@ BIS_API bis_status bis_mat_create64(bis_ctx *ctx, int64_t n_rows,
 BIS_API bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A);
 BIS_API bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows,
                                 int64_t *n_cols, int64_t *nnz);
+/* rebuild a matrix' row-block metadata after bis_set_option (tuning) */
+BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
 /* device addresses of the CRS arrays (tuning / zero-copy interop) */
 BIS_API bis_status bis_mat_debug_ptrs(const bis_mat *A, void **row_ptr,
                                       void **col, void **val);
