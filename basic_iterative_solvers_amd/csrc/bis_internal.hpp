@@ -152,6 +152,12 @@ __device__ __forceinline__ int xcd_remap(int b, int n_padded8) {
     const int per = n_padded8 >> 3;
     return (b & 7) * per + (b >> 3);
 }
+// Grouped form: within every window of 8*G consecutive logical blocks, XCD j
+// takes the G consecutive blocks [j*G, (j+1)*G).  G = 1 is blockIdx order.
+__device__ __forceinline__ int xcd_group_remap(int b, int G) {
+    const int j = b & 7, q = b >> 3;
+    return (q / G) * (8 * G) + j * G + (q % G);
+}
 
 // HIP-event bracket around one launch (bis_profile_enable)
 inline void bis_prof_begin(bis_ctx *ctx) {

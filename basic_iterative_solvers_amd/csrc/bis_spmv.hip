@@ -11,13 +11,15 @@
 //   * after one barrier each lane owns a row and sums that row's products
 //     from LDS left to right (CRS storage order, like the reference's scalar
 //     loop), then writes y coalesced;
-//   * row blocks are taken in blockIdx order: the 8 XCDs then stream ONE
-//     advancing window of val/col together.  (An XCD-aware map that gives each
-//     XCD its own contiguous slab of rows -- so that a stencil's x planes stay
-//     in one L2 -- was measured 3-9 % SLOWER on HPCG-256, 1.122 vs 1.085 ms:
-//     eight far-apart HBM streams cost more than the x re-fetches they save,
-//     which the 256 MiB Infinity Cache absorbs.  Kept as option
-//     "spmv_xcd_remap".)
+//   * XCD-aware block map, fine-grained: workgroups are dealt round-robin to
+//     the 8 XCDs, so within every window of 64 consecutive row blocks XCD j is
+//     given the 8 consecutive blocks [8j, 8j+8) (neighbouring x-lines share one
+//     L2) while all XCDs still stream ONE advancing window of val/col.  Giving
+//     each XCD its own contiguous SLAB of the matrix -- the textbook map --
+//     was measured 9 % slower (HPCG-256, same arrays: 1.109 ms slabs, 1.032
+//     plain blockIdx order, 1.012 groups of 8): eight far-apart HBM streams
+//     cost more than the x re-fetches they save, which the 256 MiB Infinity
+//     Cache absorbs.  Option "spmv_xcd_remap": 0 none, 1 slabs, G>1 groups.
 //
 // Rows longer than the LDS budget fall back to a wave-per-row kernel.
 // An optional fused epilogue accumulates sum_r y[r]*w[r] (the (Ap,p) of
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     int n_blocks_pad8, const double *w, double *partials) {
     constexpr bool FUSE_DOT = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) double prod[];
-    const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8) : (int)blockIdx.x;
+    const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8)
+                                    : (n_blocks_pad8 < -1 ? xcd_group_remap(blockIdx.x, -n_blocks_pad8) : (int)blockIdx.x);
     if (b >= n_blocks) return;
     // one dependent level only: row range and nnz range come from the block
     // table; the row_ptr entries phase 2 needs are fetched now, under phase 1
@@ -296,15 +299,15 @@ __global__ __launch_bounds__(T) void spmv_window_kernel(
 struct SpmvArgs {
     const void *row_ptr; const int32_t *col; const double *val; const double *x; double *y;
     const int32_t *blk_row; const int64_t *blk_nnz; int nb, nb8; const double *w; double *partials;
-    size_t lds_bytes; hipStream_t stream; int mode; int n_cus = 256; bool remap = false;
+    size_t lds_bytes; hipStream_t stream; int mode; int n_cus = 256; bool remap = false; int remap_arg = -1; int grid = 0;
 };
 
 template <typename RP, int T, int U, bool NT>
 void launch_variant(const SpmvArgs &a) {
 #define BIS_LV(MODE)                                                                              \
-    hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, NT, MODE>), dim3(a.nb8), dim3(T), a.lds_bytes, \
+    hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, NT, MODE>), dim3(a.grid), dim3(T), a.lds_bytes, \
                        a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y, a.blk_row, a.blk_nnz, \
-                       a.nb, a.remap ? a.nb8 : -1, a.w, a.partials)
+                       a.nb, a.remap_arg, a.w, a.partials)
     if (a.mode == 2) BIS_LV(2);
     else if (a.mode == 1) BIS_LV(1);
     else BIS_LV(0);
@@ -341,6 +344,19 @@ bool launch_by_id(int id, const SpmvArgs &a) {
 // 128-thread blocks 1.10; a lane-per-row "row-major" phase 2 (fma order) 1.23-1.30;
 // a persistent, software-pipelined grid 1.23-1.48; 64 consecutive non-zeros per
 // gather instruction (8/4-byte loads) 1.23; nontemporal val/col loads +10 %.
+// kernel argument encoding of the block map: nb8 = XCD slabs, -1 = blockIdx order, -G = groups of G
+// default: groups of 8 (HPCG-256: 1.012 ms vs 1.032 blockIdx order vs 1.109 slabs)
+int remap_arg_for(int nb8) {
+    const int r = bis_opts().spmv_xcd_remap < 0 ? 8 : bis_opts().spmv_xcd_remap;
+    return r == 1 ? nb8 : (r > 1 ? -r : -1);
+}
+
+// grid size: a whole number of windows so that every logical block id < n_blocks is produced
+int grid_for_map(int nb, int remap_arg) {
+    const int w = remap_arg < -1 ? 8 * -remap_arg : 8;
+    return (nb + w - 1) / w * w;
+}
+
 // threads per workgroup of a variant id (the fused dot writes one partial per wave)
 int fused_threads(int id) { return id >= 2000 ? 64 : id >= 1000 ? 128 : id >= 300 ? 1024 : id >= 100 ? 512 : 256; }
 
@@ -441,7 +457,9 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
                ctx->partials + partials_off, lds_bytes,
                ctx->stream, w ? 1 : 0};
     a.n_cus = ctx->n_cus;
-    a.remap = bis_opts().spmv_xcd_remap > 0;
+    a.remap = bis_opts().spmv_xcd_remap == 1;
+    a.remap_arg = remap_arg_for(nb8);
+    a.grid = grid_for_map(nb, a.remap_arg);
     bis_prof_begin(ctx);
     const bool ok = A->rp64 ? launch_by_id<int64_t>(spmv_variant(A), a)
                             : launch_by_id<int32_t>(spmv_variant(A), a);
@@ -464,7 +482,9 @@ bis_status bis_spmv_trsv_level(bis_ctx *ctx, const bis_mat *T, const double *x, 
     SpmvArgs a{T->row_ptr, T->col, T->val, x, y, T->blk_row, T->blk_nnz, nb, nb8, b,
                const_cast<double *>(D), lds_bytes, ctx->stream, 2};
     a.n_cus = ctx->n_cus;
-    a.remap = bis_opts().spmv_xcd_remap > 0;
+    a.remap = bis_opts().spmv_xcd_remap == 1;
+    a.remap_arg = remap_arg_for(nb8);
+    a.grid = grid_for_map(nb, a.remap_arg);
     const bool ok = T->rp64 ? launch_by_id<int64_t>(spmv_variant(T), a) : launch_by_id<int32_t>(spmv_variant(T), a);
     if (!ok) return BIS_ERR_INVALID;
     BIS_HIP_CHECK(ctx, hipGetLastError());
