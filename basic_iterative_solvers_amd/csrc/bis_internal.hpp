@@ -56,6 +56,8 @@ struct bis_options {
     int spmv_chunk_fused = -1; // -1: default (2048) for the SpMV with the fused dot epilogue
     int spmv_xcd_remap = -1; // 1: each XCD sweeps its own slab of row blocks (default: blockIdx order)
     int trsv_grid = -1;    // -1: automatic
+    int spmv_lds_pad = -1; // diagnostic: extra dynamic LDS bytes per workgroup (lowers occupancy)
+    int spmv_packed = -1;  // 16-bit packed column stream: 0 off, 1 select tree, 2 lane permute (-1: default = 1)
 };
 bis_options &bis_opts();
 
@@ -84,6 +86,15 @@ struct bis_mat {
     int max_tiles = 0;
     bool win_ok = false;
     int n_blocks = 0;
+    // packed-column streams (bis_spmv.hip), one per row-block table (0 plain, 1
+    // fused): per non-zero a 16-bit code (segment:3 | offset:13) against 8 column
+    // bases per row block -- 10 instead of 12 streamed bytes per non-zero.  Built
+    // lazily at the first SpMV; state 0 = not tried, 1 = usable, -1 = not
+    // representable (some block needs more than 8 windows of 8192 columns).
+    uint16_t *pk[2] = {nullptr, nullptr};
+    int32_t *pk_seg[2] = {nullptr, nullptr}; // [n_blocks * 8]
+    int64_t pk_base[2] = {0, 0};
+    int pk_state[2] = {0, 0};
     // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
     int32_t *blkf_row = nullptr;
     int64_t *blkf_nnz = nullptr;
@@ -198,6 +209,11 @@ bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols,
                          int64_t nnz, bool rp64, bis_mat **out);
 bis_status bis_mat_finalize(bis_ctx *ctx, bis_mat *A);
 bis_status bis_spmv_build_window(bis_ctx *ctx, bis_mat *A);
+void bis_spmv_drop_packed(bis_mat *A);
+// try to build the packed-column stream of table t (0 plain, 1 fused); A->pk_state[t] tells the outcome
+bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t);
+// free row-block tables, packed streams and window structures (not the CRS arrays)
+void bis_mat_free_meta(bis_mat *A);
 void bis_trsv_plan_destroy(bis_trsv_plan *p);
 bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
                                      bis_mat **U_strict, double *D, double *D_inv, bool check_diag);

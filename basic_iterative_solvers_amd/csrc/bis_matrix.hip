@@ -263,34 +263,55 @@ bis_status finalize_t(bis_ctx *ctx, bis_mat *A) {
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     A->max_row_nnz = h_max;
-    // two row-block tables: plain SpMV / triangular sweeps (chunk 1024) and the
-    // SpMV with the fused dot epilogue of CG (chunk 2048) -- tools/spmv_ab.py,
-    // tools/cg_ab.py: 1.02 vs 1.08 ms plain, 1.14 vs 1.03 ms fused on HPCG-256
-    const int chunks[2] = {bis_opts().spmv_chunk > 0 ? std::max(256, bis_opts().spmv_chunk) : 1024,
-                           bis_opts().spmv_chunk_fused > 0 ? std::max(256, bis_opts().spmv_chunk_fused) : 2048};
+    // Row-block tables (0: plain SpMV / triangular sweeps, 1: SpMV with the fused
+    // dot epilogue of CG).  With the packed column stream both use one pass of the
+    // 256-thread kernel with 2 staged vectors per lane: chunk = 2048 - max_row - 4,
+    // so that no block exceeds 2048 stream positions (tools/spmv_ab.py, HPCG-256,
+    // same arrays: 0.95 ms against 0.99 at chunk 990).  If some block cannot be
+    // packed (more than 8 column windows) the 32-bit stream keeps its own tuning:
+    // chunk 1024 plain / 2048 fused (1.03 vs 1.10 ms plain, 1.14 vs 1.11 ms fused).
+    const bool user_chunks = bis_opts().spmv_chunk > 0 || bis_opts().spmv_chunk_fused > 0;
+    const int packed_mode = bis_opts().spmv_packed < 0 ? 1 : bis_opts().spmv_packed;
     int32_t **rows[2] = {&A->blk_row, &A->blkf_row};
     int64_t **nnzs[2] = {&A->blk_nnz, &A->blkf_nnz};
     int *counts[2] = {&A->n_blocks, &A->n_blocks_f};
     int *chk[2] = {&A->chunk_nnz, &A->chunk_f};
-    for (int t = 0; t < 2; ++t) {
-        const int chunk = chunks[t];
-        *chk[t] = chunk;
-        int64_t nb = (A->nnz + A->n_rows + chunk - 1) / chunk;
-        if (nb < 1) nb = 1;
-        *counts[t] = (int)nb;
-        if (*rows[t]) hipFree(*rows[t]);
-        if (*nnzs[t]) hipFree(*nnzs[t]);
-        *rows[t] = nullptr; *nnzs[t] = nullptr;
-        BIS_HIP_CHECK(ctx, hipMalloc(rows[t], sizeof(int32_t) * (size_t)(nb + 1)));
-        BIS_HIP_CHECK(ctx, hipMalloc(nnzs[t], sizeof(int64_t) * (size_t)(nb + 1)));
-        hipLaunchKernelGGL(row_blocks_kernel<RP>, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0,
-                           ctx->stream, rp, A->n_rows, (int)nb, (int64_t)chunk, *rows[t], *nnzs[t]);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int chunks[2] = {bis_opts().spmv_chunk > 0 ? std::max(256, bis_opts().spmv_chunk) : 1024,
+                         bis_opts().spmv_chunk_fused > 0 ? std::max(256, bis_opts().spmv_chunk_fused) : 2048};
+        const bool try_single = attempt == 0 && packed_mode != 0 && !user_chunks && A->nnz > 0;
+        if (try_single) chunks[0] = chunks[1] = std::max(256, 2048 - h_max - 4);
+        bis_mat_free_meta(A);
+        for (int t = 0; t < 2; ++t) {
+            const int chunk = chunks[t];
+            *chk[t] = chunk;
+            int64_t nb = (A->nnz + A->n_rows + chunk - 1) / chunk;
+            if (nb < 1) nb = 1;
+            *counts[t] = (int)nb;
+            BIS_HIP_CHECK(ctx, hipMalloc(rows[t], sizeof(int32_t) * (size_t)(nb + 1)));
+            BIS_HIP_CHECK(ctx, hipMalloc(nnzs[t], sizeof(int64_t) * (size_t)(nb + 1)));
+            hipLaunchKernelGGL(row_blocks_kernel<RP>, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0,
+                               ctx->stream, rp, A->n_rows, (int)nb, (int64_t)chunk, *rows[t], *nnzs[t]);
+        }
+        BIS_HIP_CHECK(ctx, hipGetLastError());
+        if (!try_single) break;
+        if (bis_status st = bis_spmv_try_pack(ctx, A, 1)) return st;
+        if (A->pk_state[1] == 1) break; // packed: keep the single-pass tables
     }
-    BIS_HIP_CHECK(ctx, hipGetLastError());
     return bis_spmv_build_window(ctx, A);
 }
 
 } // namespace
+
+void bis_mat_free_meta(bis_mat *A) {
+    hipFree(A->blk_row); hipFree(A->blk_nnz); hipFree(A->blkf_row); hipFree(A->blkf_nnz);
+    A->blk_row = A->blkf_row = nullptr;
+    A->blk_nnz = A->blkf_nnz = nullptr;
+    bis_spmv_drop_packed(A);
+    hipFree(A->loc); hipFree(A->tiles); hipFree(A->tile_cnt);
+    A->loc = nullptr; A->tiles = nullptr; A->tile_cnt = nullptr;
+    A->win_ok = false;
+}
 
 bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, bool rp64,
                          bis_mat **out) {
@@ -416,13 +437,7 @@ bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A) {
         hipFree(A->col);
         hipFree(A->val);
     }
-    hipFree(A->blk_row);
-    hipFree(A->blk_nnz);
-    hipFree(A->blkf_row);
-    hipFree(A->blkf_nnz);
-    hipFree(A->loc);
-    hipFree(A->tiles);
-    hipFree(A->tile_cnt);
+    bis_mat_free_meta(A);
     delete A;
     return BIS_OK;
 }

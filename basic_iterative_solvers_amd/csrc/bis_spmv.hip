@@ -33,10 +33,30 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-template <bool NT, typename V>
-__device__ __forceinline__ V stream_load(const V *p) {
-    if (NT) return __builtin_nontemporal_load(p);
-    return *p;
+typedef unsigned short v4us __attribute__((ext_vector_type(4)));
+
+// x[c]: with fewer than 2^29 columns the byte offset fits 32 bits (one shift,
+// scalar base + 32-bit vector offset addressing); WIDE keeps 64-bit arithmetic.
+template <bool WIDE>
+__device__ __forceinline__ double x_at(const char *xb, int c) {
+    if (WIDE) return *reinterpret_cast<const double *>(xb + (int64_t)c * 8);
+    return *reinterpret_cast<const double *>(xb + (uint32_t)((uint32_t)c << 3));
+}
+
+constexpr int kPkSegs = 8, kPkOffBits = 13, kPkSpan = 1 << kPkOffBits;
+
+template <int PK>
+__device__ __forceinline__ int pk_decode(unsigned code, const int (&B)[8], int lane_base, int col_max) {
+    int base;
+    if (PK == 2) {
+        base = __builtin_amdgcn_ds_bpermute((int)((code >> (kPkOffBits - 2)) & 28u), lane_base);
+    } else {
+        const bool b0 = code & (1u << kPkOffBits), b1 = code & (2u << kPkOffBits), b2 = code & (4u << kPkOffBits);
+        const int a0 = b0 ? B[1] : B[0], a1 = b0 ? B[3] : B[2], a2 = b0 ? B[5] : B[4], a3 = b0 ? B[7] : B[6];
+        const int c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2;
+        base = b2 ? c1 : c0;
+    }
+    return min(base + (int)(code & (kPkSpan - 1)), col_max);
 }
 
 // T threads; U = 4-non-zero vectors staged per lane before the first use
@@ -47,12 +67,20 @@ __device__ __forceinline__ V stream_load(const V *p) {
 // range: y[r] = (w[r] - (A x)[r]) / dinv_or_d[r], i.e. x_level = (b - T x)/D
 // (kernels.hpp:70,102); y may be the same array as x -- rows of one level do
 // not reference each other.
-template <typename RP, int T, int U, bool NT, int MODE>
+//
+// PK != 0: the column stream is the packed one (2 B per non-zero): code =
+// segment:3 | offset:13, column = seg_base[8*b + segment] + offset.  PK 1 picks
+// the base with a select tree over 8 registers, PK 2 with one cross-lane
+// permute (lane j < 8 of every wave holds base j).  Codes of the neighbouring
+// blocks that share the first/last 4-aligned vector decode against the wrong
+// bases: clamped to a valid column, their products are never read.
+template <typename RP, int T, int U, int PK, int MODE, bool WIDE = false, int BR = 0>
 __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
     const double *__restrict__ val, const double *x, double *y,
     const int32_t *__restrict__ blk_row, const int64_t *__restrict__ blk_nnz, int n_blocks,
-    int n_blocks_pad8, const double *w, double *partials) {
+    int n_blocks_pad8, const double *w, double *partials, const uint16_t *__restrict__ pk,
+    int64_t pk_base, const int32_t *__restrict__ seg_base, int col_max) {
     constexpr bool FUSE_DOT = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) double prod[];
     const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8)
@@ -66,39 +94,133 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     const int my_r = r0 + (int)threadIdx.x;
     RP rp_a = 0, rp_z = 0;
     if (my_r < r1) { rp_a = row_ptr[my_r]; rp_z = row_ptr[my_r + 1]; }
+    int segb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int lane_base = 0;
+    if (PK == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) segb[i] = seg_base[(size_t)b * 8 + i];
+    }
+    if (PK == 2) lane_base = seg_base[(size_t)b * 8 + (threadIdx.x & 7)];
+    const char *xb = reinterpret_cast<const char *>(x);
 
-    // phase 1: stream val/col, gather x, park products
-    for (int64_t k0 = s4 + 4 * (int64_t)threadIdx.x; k0 < e; k0 += 4 * T * U) {
+    // phase 1: stream val/col, gather x, park products.  Branch-free up to the
+    // LDS store: lanes past the block's end re-read its last vector (clamped
+    // index), so every load and gather of all U stages is in flight before
+    // the first use and the wave stays whole (the lane permute needs that).
+    if (BR == 2) {
+        // consecutive form: lane t of the workgroup takes non-zeros base + j*T + t, so
+        // one gather instruction covers 64 consecutive non-zeros (neighbouring lanes
+        // mostly share an x cache line); narrow (8 B / 4 B / 2 B) but fully coalesced
+        // stream loads, conflict-free LDS stores.  No alignment slack: prod[k - s4]
+        // keeps the index convention of the other forms.
+        constexpr int J = 4 * U;
+        for (int64_t base = s; base < e; base += (int64_t)J * T) {
+            int cc[J];
+            double vv[J], xx[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int64_t k = min(base + (int64_t)j * T + threadIdx.x, e - 1);
+                if (PK) cc[j] = pk[k - pk_base];
+                else cc[j] = col[k];
+                vv[j] = val[k];
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (PK) cc[j] = pk_decode<PK>((unsigned)cc[j], segb, lane_base, col_max);
+                xx[j] = x_at<WIDE>(xb, cc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int64_t k = base + (int64_t)j * T + threadIdx.x;
+                double pr = vv[j] * xx[j];
+                asm volatile("" : "+v"(pr));
+                if (k < e) prod[k - s4] = pr;
+            }
+        }
+    } else if (BR == 1) { // staged, predicated form (each stage waits for its own gathers)
+        for (int64_t k0 = s4 + 4 * (int64_t)threadIdx.x; k0 < e; k0 += 4 * T * U) {
+            v4i c[U];
+            v4us pc[U];
+            v2d va[U], vb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = k0 + (int64_t)u * 4 * T;
+                if (k < e) {
+                    if (PK) pc[u] = *reinterpret_cast<const v4us *>(pk + (k - pk_base));
+                    else c[u] = *reinterpret_cast<const v4i *>(col + k);
+                    va[u] = *reinterpret_cast<const v2d *>(val + k);
+                    vb[u] = *reinterpret_cast<const v2d *>(val + k + 2);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = k0 + (int64_t)u * 4 * T;
+                if (k < e) {
+                    if (PK) {
+                        c[u].x = pk_decode<PK>(pc[u].x, segb, lane_base, col_max);
+                        c[u].y = pk_decode<PK>(pc[u].y, segb, lane_base, col_max);
+                        c[u].z = pk_decode<PK>(pc[u].z, segb, lane_base, col_max);
+                        c[u].w = pk_decode<PK>(pc[u].w, segb, lane_base, col_max);
+                    }
+                    va[u].x *= x[c[u].x];
+                    va[u].y *= x[c[u].y];
+                    vb[u].x *= x[c[u].z];
+                    vb[u].y *= x[c[u].w];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = k0 + (int64_t)u * 4 * T;
+                if (k < e) {
+                    v2d *dst = reinterpret_cast<v2d *>(prod + (k - s4));
+                    dst[0] = va[u];
+                    dst[1] = vb[u];
+                }
+            }
+        }
+    } else {
+    const int64_t k_last = (e - 1) & ~(int64_t)3;
+    for (int64_t base = s4; base < e; base += 4 * T * U) {
         v4i c[U];
+        v4us pc[U];
         v2d va[U], vb[U];
+        double xv[U][4];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t k = k0 + (int64_t)u * 4 * T;
-            if (k < e) {
-                c[u] = stream_load<NT>(reinterpret_cast<const v4i *>(col + k));
-                va[u] = stream_load<NT>(reinterpret_cast<const v2d *>(val + k));
-                vb[u] = stream_load<NT>(reinterpret_cast<const v2d *>(val + k + 2));
-            }
+            const int64_t k = min(base + 4 * (int64_t)threadIdx.x + (int64_t)u * 4 * T, k_last);
+            if (PK) pc[u] = *reinterpret_cast<const v4us *>(pk + (k - pk_base));
+            else c[u] = *reinterpret_cast<const v4i *>(col + k);
+            va[u] = *reinterpret_cast<const v2d *>(val + k);
+            vb[u] = *reinterpret_cast<const v2d *>(val + k + 2);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t k = k0 + (int64_t)u * 4 * T;
-            if (k < e) {
-                va[u].x *= x[c[u].x];
-                va[u].y *= x[c[u].y];
-                vb[u].x *= x[c[u].z];
-                vb[u].y *= x[c[u].w];
+            if (PK) {
+                c[u].x = pk_decode<PK>(pc[u].x, segb, lane_base, col_max);
+                c[u].y = pk_decode<PK>(pc[u].y, segb, lane_base, col_max);
+                c[u].z = pk_decode<PK>(pc[u].z, segb, lane_base, col_max);
+                c[u].w = pk_decode<PK>(pc[u].w, segb, lane_base, col_max);
             }
+            xv[u][0] = x_at<WIDE>(xb, c[u].x);
+            xv[u][1] = x_at<WIDE>(xb, c[u].y);
+            xv[u][2] = x_at<WIDE>(xb, c[u].z);
+            xv[u][3] = x_at<WIDE>(xb, c[u].w);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t k = k0 + (int64_t)u * 4 * T;
+            const int64_t k = base + 4 * (int64_t)threadIdx.x + (int64_t)u * 4 * T;
+            double p0 = va[u].x * xv[u][0], p1 = va[u].y * xv[u][1];
+            double p2 = vb[u].x * xv[u][2], p3 = vb[u].y * xv[u][3];
+            // pin the products here: otherwise the val loads sink into the
+            // predicated store below and leave the load stage
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
             if (k < e) {
                 v2d *dst = reinterpret_cast<v2d *>(prod + (k - s4));
-                dst[0] = va[u];
-                dst[1] = vb[u];
+                dst[0] = v2d{p0, p1};
+                dst[1] = v2d{p2, p3};
             }
         }
+    }
     }
     __syncthreads();
 
@@ -207,8 +329,6 @@ __global__ __launch_bounds__(256) void window_build_kernel(
     }
 }
 
-typedef unsigned short v4us __attribute__((ext_vector_type(4)));
-
 template <typename RP, int T, int U, bool FUSE_DOT>
 __global__ __launch_bounds__(T) void spmv_window_kernel(
     const RP *__restrict__ row_ptr, const uint16_t *__restrict__ loc, int64_t loc_base,
@@ -296,44 +416,95 @@ __global__ __launch_bounds__(T) void spmv_window_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Packed-column analysis, one workgroup per row block: cover the block's
+// columns greedily with windows [base, base + 8192) taken at the smallest
+// uncovered column (so the bases come out ascending); more than 8 windows ->
+// the matrix keeps the 32-bit column stream.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pk_build_kernel(const int32_t *__restrict__ col,
+                                                       const int64_t *__restrict__ blk_nnz, int n_blocks,
+                                                       int64_t pk_base, uint16_t *__restrict__ pk,
+                                                       int32_t *__restrict__ seg_base, int *__restrict__ status) {
+    __shared__ int base[kPkSegs];
+    __shared__ int cur;
+    const int b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const int64_t s = blk_nnz[b], e = blk_nnz[b + 1];
+    int n_seg = 0;
+    for (int sg = 0; sg <= kPkSegs; ++sg) {
+        if (threadIdx.x == 0) cur = INT32_MAX;
+        __syncthreads();
+        int m = INT32_MAX;
+        for (int64_t k = s + threadIdx.x; k < e; k += 256) {
+            const int c = col[k];
+            bool covered = false;
+            for (int i = 0; i < sg; ++i) covered |= (c >= base[i] && c - base[i] < kPkSpan);
+            if (!covered) m = min(m, c);
+        }
+        if (m != INT32_MAX) atomicMin(&cur, m);
+        __syncthreads();
+        const int found = cur;
+        __syncthreads();
+        if (found == INT32_MAX) break;
+        if (sg == kPkSegs) { // a ninth window would be needed
+            if (threadIdx.x == 0) atomicExch(&status[0], 1);
+            return;
+        }
+        if (threadIdx.x == 0) base[sg] = found;
+        n_seg = sg + 1;
+        __syncthreads();
+    }
+    if (threadIdx.x < kPkSegs) seg_base[(size_t)b * kPkSegs + threadIdx.x] = (int)threadIdx.x < n_seg ? base[threadIdx.x] : 0;
+    for (int64_t k = s + threadIdx.x; k < e; k += 256) {
+        const int c = col[k];
+        int sg = 0;
+        for (int i = 1; i < n_seg; ++i) sg += base[i] <= c; // ascending bases: last one not above c
+        pk[k - pk_base] = (uint16_t)((sg << kPkOffBits) | (c - base[sg]));
+    }
+}
+
 struct SpmvArgs {
     const void *row_ptr; const int32_t *col; const double *val; const double *x; double *y;
     const int32_t *blk_row; const int64_t *blk_nnz; int nb, nb8; const double *w; double *partials;
     size_t lds_bytes; hipStream_t stream; int mode; int n_cus = 256; bool remap = false; int remap_arg = -1; int grid = 0;
+    const uint16_t *pk = nullptr; int64_t pk_base = 0; const int32_t *seg_base = nullptr; int col_max = 0; int pk_mode = 0;
+    bool wide = false; // 2^29 columns or more: 64-bit x addressing, 32-bit column stream
 };
 
-template <typename RP, int T, int U, bool NT>
+template <typename RP, int T, int U, int BR = 0>
 void launch_variant(const SpmvArgs &a) {
-#define BIS_LV(MODE)                                                                              \
-    hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, NT, MODE>), dim3(a.grid), dim3(T), a.lds_bytes, \
+#define BIS_LV(PK, MODE)                                                                          \
+    hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, (PK) < 0 ? 0 : (PK), MODE, (PK) < 0, BR>), dim3(a.grid), dim3(T), a.lds_bytes, \
                        a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y, a.blk_row, a.blk_nnz, \
-                       a.nb, a.remap_arg, a.w, a.partials)
-    if (a.mode == 2) BIS_LV(2);
-    else if (a.mode == 1) BIS_LV(1);
-    else BIS_LV(0);
+                       a.nb, a.remap_arg, a.w, a.partials, a.pk, a.pk_base, a.seg_base, a.col_max)
+#define BIS_LVM(PK)                                                                               \
+    do {                                                                                          \
+        if (a.mode == 2) BIS_LV(PK, 2);                                                           \
+        else if (a.mode == 1) BIS_LV(PK, 1);                                                      \
+        else BIS_LV(PK, 0);                                                                       \
+    } while (0)
+    if (a.wide) BIS_LVM(-1);
+    else if (a.pk_mode == 1) BIS_LVM(1);
+    else if (a.pk_mode == 2) BIS_LVM(2);
+    else BIS_LVM(0);
+#undef BIS_LVM
 #undef BIS_LV
 }
 
-// variant id = T/256-1 (0,1,3) * 100 + U * 10 + NT      (tuning knob BIS_SPMV_VARIANT)
+// variant id: 10/20/40 = 256 threads with U = 1/2/4 staged vectors per lane
+// (tuning knob BIS_SPMV_VARIANT)
 template <typename RP>
 bool launch_by_id(int id, const SpmvArgs &a) {
     switch (id) {
-    case 10: launch_variant<RP, 256, 1, false>(a); return true;
-    case 11: launch_variant<RP, 256, 1, true>(a); return true;
-    case 20: launch_variant<RP, 256, 2, false>(a); return true;
-    case 21: launch_variant<RP, 256, 2, true>(a); return true;
-    case 40: launch_variant<RP, 256, 4, false>(a); return true;
-    case 41: launch_variant<RP, 256, 4, true>(a); return true;
-    case 1040: launch_variant<RP, 128, 4, false>(a); return true;
-    case 1020: launch_variant<RP, 128, 2, false>(a); return true;
-    case 2040: launch_variant<RP, 64, 4, false>(a); return true;
-    case 2080: launch_variant<RP, 64, 8, false>(a); return true;
-    case 120: launch_variant<RP, 512, 2, false>(a); return true;
-    case 121: launch_variant<RP, 512, 2, true>(a); return true;
-    case 140: launch_variant<RP, 512, 4, false>(a); return true;
-    case 141: launch_variant<RP, 512, 4, true>(a); return true;
-    case 320: launch_variant<RP, 1024, 2, false>(a); return true;
-    case 321: launch_variant<RP, 1024, 2, true>(a); return true;
+    case 10: launch_variant<RP, 256, 1>(a); return true;
+    case 20: launch_variant<RP, 256, 2>(a); return true;
+    case 40: launch_variant<RP, 256, 4>(a); return true;
+    case 11: launch_variant<RP, 256, 1, 1>(a); return true;
+    case 21: launch_variant<RP, 256, 2, 1>(a); return true;
+    case 41: launch_variant<RP, 256, 4, 1>(a); return true;
+    case 12: launch_variant<RP, 256, 1, 2>(a); return true;
+    case 22: launch_variant<RP, 256, 2, 2>(a); return true;
     default: return false;
     }
 }
@@ -358,9 +529,10 @@ int grid_for_map(int nb, int remap_arg) {
 }
 
 // threads per workgroup of a variant id (the fused dot writes one partial per wave)
-int fused_threads(int id) { return id >= 2000 ? 64 : id >= 1000 ? 128 : id >= 300 ? 1024 : id >= 100 ? 512 : 256; }
+int fused_threads(int) { return 256; }
 
-int spmv_variant(const bis_mat *) { return bis_opts().spmv_variant < 0 ? 40 : bis_opts().spmv_variant; }
+// default: the branch-free 2-stage form with the packed stream, the staged 4-deep form with 32-bit columns
+int spmv_variant(const SpmvArgs &a) { return bis_opts().spmv_variant >= 0 ? bis_opts().spmv_variant : (a.pk_mode ? 20 : 41); }
 
 } // namespace
 
@@ -404,6 +576,66 @@ bis_status bis_spmv_build_window(bis_ctx *ctx, bis_mat *A) {
     }
     A->max_tiles = h[1];
     A->win_ok = true;
+    return BIS_OK;
+}
+
+void bis_spmv_drop_packed(bis_mat *A) {
+    for (int t = 0; t < 2; ++t) {
+        hipFree(A->pk[t]); hipFree(A->pk_seg[t]);
+        A->pk[t] = nullptr; A->pk_seg[t] = nullptr; A->pk_state[t] = 0;
+    }
+}
+
+// default: select tree (see the tuning record in DESIGN.md section 4)
+static int spmv_packed_mode() { return bis_opts().spmv_packed < 0 ? 1 : bis_opts().spmv_packed; }
+
+bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t) {
+    if (A->pk_state[t] != 0) return BIS_OK;
+    A->pk_state[t] = -1;
+    if (A->nnz == 0 || A->n_cols >= ((int64_t)1 << 29)) return BIS_OK;
+    const int nb = t ? A->n_blocks_f : A->n_blocks;
+    const int64_t *tab = t ? A->blkf_nnz : A->blk_nnz;
+    int64_t ends[2];
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[0], tab, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[1], tab + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    A->pk_base[t] = ends[0] & ~(int64_t)3;
+    const size_t n_pk = (size_t)(ends[1] - A->pk_base[t]) + 16;
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->pk[t], sizeof(uint16_t) * n_pk));
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->pk_seg[t], sizeof(int32_t) * (size_t)nb * kPkSegs));
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(A->pk[t], 0, sizeof(uint16_t) * n_pk, ctx->stream));
+    int *status = (int *)ctx->counters + 44;
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(pk_build_kernel, dim3(nb), dim3(256), 0, ctx->stream, A->col, tab, nb, A->pk_base[t],
+                       A->pk[t], A->pk_seg[t], status);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    int h = 0;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h) {
+        hipFree(A->pk[t]); hipFree(A->pk_seg[t]);
+        A->pk[t] = nullptr; A->pk_seg[t] = nullptr;
+    } else {
+        A->pk_state[t] = 1;
+    }
+    return BIS_OK;
+}
+
+// The packed stream of table t, built at the first use unless bis_mat_finalize
+// already did (a cache on the matrix: the const handle of the SpMV entry points
+// is cast away here only).  Identical tables (packed default) share stream 1.
+static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArgs *a) {
+    bis_mat *A = const_cast<bis_mat *>(A_c);
+    a->pk_mode = 0;
+    a->wide = A->n_cols >= ((int64_t)1 << 29);
+    if (a->wide || !spmv_packed_mode() || A->nnz == 0) return BIS_OK;
+    if (A->chunk_nnz == A->chunk_f) t = 1;
+    if (bis_status st = bis_spmv_try_pack(ctx, A, t)) return st;
+    if (A->pk_state[t] == 1) {
+        a->pk = A->pk[t]; a->pk_base = A->pk_base[t]; a->seg_base = A->pk_seg[t];
+        a->col_max = (int)std::max<int64_t>(A->n_cols - 1, 0);
+        a->pk_mode = spmv_packed_mode() == 2 ? 2 : 1;
+    }
     return BIS_OK;
 }
 
@@ -460,13 +692,15 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     a.remap = bis_opts().spmv_xcd_remap == 1;
     a.remap_arg = remap_arg_for(nb8);
     a.grid = grid_for_map(nb, a.remap_arg);
+    if (bis_status st = ensure_packed(ctx, A, use_f ? 1 : 0, &a)) return st;
+    if (bis_opts().spmv_lds_pad > 0) a.lds_bytes += (size_t)bis_opts().spmv_lds_pad;
     bis_prof_begin(ctx);
-    const bool ok = A->rp64 ? launch_by_id<int64_t>(spmv_variant(A), a)
-                            : launch_by_id<int32_t>(spmv_variant(A), a);
+    const bool ok = A->rp64 ? launch_by_id<int64_t>(spmv_variant(a), a)
+                            : launch_by_id<int32_t>(spmv_variant(a), a);
     bis_prof_end(ctx);
     if (!ok) { ctx->err = "bis_spmv: unknown BIS_SPMV_VARIANT"; return BIS_ERR_INVALID; }
     BIS_HIP_CHECK(ctx, hipGetLastError());
-    if (w && n_partials) *n_partials = nb * (fused_threads(spmv_variant(A)) / 64);
+    if (w && n_partials) *n_partials = nb * (fused_threads(spmv_variant(a)) / 64);
     return BIS_OK;
 }
 
@@ -485,7 +719,8 @@ bis_status bis_spmv_trsv_level(bis_ctx *ctx, const bis_mat *T, const double *x, 
     a.remap = bis_opts().spmv_xcd_remap == 1;
     a.remap_arg = remap_arg_for(nb8);
     a.grid = grid_for_map(nb, a.remap_arg);
-    const bool ok = T->rp64 ? launch_by_id<int64_t>(spmv_variant(T), a) : launch_by_id<int32_t>(spmv_variant(T), a);
+    if (bis_status st = ensure_packed(ctx, T, 0, &a)) return st;
+    const bool ok = T->rp64 ? launch_by_id<int64_t>(spmv_variant(a), a) : launch_by_id<int32_t>(spmv_variant(a), a);
     if (!ok) return BIS_ERR_INVALID;
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;

@@ -48,7 +48,7 @@ void bis_trsv_plan_destroy(bis_trsv_plan *p) {
     hipFree(p->xs);
     hipFree(p->ticket);
     for (bis_mat *v : p->level_views) { // row views: only their block tables are theirs
-        hipFree(v->blk_row); hipFree(v->blk_nnz); hipFree(v->blkf_row); hipFree(v->blkf_nnz); hipFree(v->loc); hipFree(v->tiles); hipFree(v->tile_cnt);
+        bis_mat_free_meta(v);
         delete v;
     }
     delete p;

@@ -16,7 +16,7 @@ b, x = ctx.alloc(N), ctx.alloc(N)
 res = [[] for _ in cfgs]
 for rnd in range(int(os.environ.get("ROUNDS", "4"))):
     for i, c in enumerate(cfgs):
-        for k in ("variant", "chunk_fused", "window", "xcd_remap"):
+        for k in ("variant", "chunk_fused", "window", "xcd_remap", "packed"):
             lib.bis_set_option(("spmv_" + k).encode(), int(c.get({"xcd_remap": "remap", "chunk_fused": "chunk"}.get(k, k), -1)))
         ctx.check(lib.bis_mat_retune(ctx.h, A.h))
         ctx.init_vector(b, 1.0); ctx.init_vector(x, 0.1)

@@ -24,7 +24,7 @@ b = 12 * A.nnz + 20 * N
 times = [[] for _ in cfgs]
 for rnd in range(int(os.environ.get("ROUNDS", "5"))):
     for i, c in enumerate(cfgs):
-        for k in ("variant", "chunk", "window", "xcd_remap"):
+        for k in ("variant", "chunk", "window", "xcd_remap", "packed", "lds_pad"):
             lib.bis_set_option(("spmv_" + k).encode(), int(c.get(k if k != "xcd_remap" else "remap", -1)))
         ctx.check(lib.bis_mat_retune(ctx.h, A.h))
         for _ in range(2): ctx.spmv(A, x, y)
