@@ -236,6 +236,8 @@ bis_status bis_dist_create(bis_ctx *ctx, bis_mat *A, int rank, int n_ranks, cons
         return BIS_ERR_HIP;
     }
     A->n_cols = d->n_local + d->n_halo;
+    st = bis_mat_finalize(ctx, A); // the column indices changed: rebuild the packed stream / window structures
+    if (st != BIS_OK) { hipEventDestroy(d->ev_packed); hipEventDestroy(d->ev_halo); hipStreamDestroy(d->comm_stream); delete d; return st; }
     d->A = A;
     d->mid_a = interior[0];
     d->mid_b = interior[1];

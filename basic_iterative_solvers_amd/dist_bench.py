@@ -34,7 +34,7 @@ def run_distributed(args, rank, world, local_rank):
     try:
         setup_rccl(ctx, d, td, group=host_group)
         ok = 1
-    except BisError as ex:  # e.g. RCCL not loadable: fall back to torch.distributed's communicator
+XX
         print(f"rank {rank}: native RCCL transport unavailable ({ex}); using torch.distributed", flush=True)
         ok = 0
     flag = torch.tensor([ok], device="cuda")
