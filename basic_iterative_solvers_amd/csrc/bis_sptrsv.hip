@@ -32,6 +32,8 @@
 struct bis_trsv_plan {
     int32_t *perm = nullptr; // device, rows sorted by level
     double *xs = nullptr;    // device scratch, sentinel-filled before each solve
+    bool no_pos = false;
+    int32_t *pcol = nullptr; // device: position (in perm) of every column -- the scratch is kept in level order
     unsigned *ticket = nullptr;
     int n_levels = 0;
     int64_t n = 0;
@@ -46,6 +48,7 @@ void bis_trsv_plan_destroy(bis_trsv_plan *p) {
     if (!p) return;
     hipFree(p->perm);
     hipFree(p->xs);
+    hipFree(p->pcol);
     hipFree(p->ticket);
     for (bis_mat *v : p->level_views) { // row views: only their block tables are theirs
         bis_mat_free_meta(v);
@@ -59,20 +62,41 @@ namespace {
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
 constexpr int kTrsvT = 256;
-constexpr int kBatch = 8; // dependencies polled per round trip
+constexpr unsigned kSpinLimit = 1u << 22; // polls of one row before it gives up and publishes NaN (seconds)
 
 __global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned long long *xs, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) xs[i] = kSentinel;
 }
 
-template <typename RP>
+// ONE_XCD: the persistent grid elects the XCD of the first workgroup that arrives
+// (HW_REG_XCC_ID, hardware truth -- not a blockIdx convention) and every workgroup
+// on another XCD leaves at once.  All participants then share ONE L2, so results
+// are published with plain stores (the line stays in that L2) and polled with
+// L1-bypassing loads served by the same L2: a hand-off costs an L2 round trip
+// instead of two trips through the fabric.  Any placement is correct (at least the
+// electing workgroup takes part, tickets are only taken by participants); the
+// placement decides only how many workgroups help.
+template <typename RP, bool ONE_XCD, int kBatch>
 __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
-    const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+    const RP *__restrict__ row_ptr, const int32_t *__restrict__ dep /* col, or positions (pcol) */,
     const double *__restrict__ val, const int32_t *__restrict__ perm, int64_t n,
     const double *__restrict__ D, const double *b, double *x, unsigned long long *xs,
-    unsigned *ticket) {
+    unsigned *ticket, int by_pos) {
     __shared__ unsigned s_ticket;
+    if (ONE_XCD) {
+        if (threadIdx.x == 0) {
+            unsigned my;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+            my &= 0xfu;
+            const unsigned prev = atomicCAS(ticket + 1, 0xffffffffu, my);
+            s_ticket = (prev == 0xffffffffu || prev == my) ? 1u : 0u;
+        }
+        __syncthreads();
+        const unsigned go = s_ticket;
+        __syncthreads();
+        if (!go) return;
+    }
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
         __syncthreads();
@@ -86,43 +110,106 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
             int64_t k = (int64_t)row_ptr[r];
             const int64_t e = (int64_t)row_ptr[r + 1];
             const double rhs = b[r], d = D[r];
+            const int64_t slot = by_pos ? pos : (int64_t)r; // where this row's result is published
             double acc = 0.0;
+            unsigned spins = 0;
+            // One loop, bounded work per trip (lanes of one wave may depend on each
+            // other, so no lane may spin in a loop of its own): a batch of up to
+            // kBatch dependencies is loaded with independent loads (one round trip),
+            // the ready prefix is consumed IN ORDER (the sum keeps CRS order), and
+            // only the words that were still pending are polled again, together.
+            unsigned long long bits[kBatch];
+            double av[kBatch];
+            int pc[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) { bits[j] = kSentinel; av[j] = 0.0; pc[j] = 0; }
+            int ready = 0, in_batch = 0; // ready == in_batch: batch exhausted, load the next one
+            // NOTE the publishing store must execute INSIDE the loop: a block that always
+            // leaves the loop (a `break`, or a flag the compiler can see through) is an exit
+            // block, and exit blocks run only after EVERY lane of the wave has left the
+            // loop -- the store would wait for the very lanes that wait for it.
             bool done = false;
             while (!done) {
-                // Poll up to kBatch pending dependencies with independent loads (one
-                // memory round trip for the batch, not one per dependency), then
-                // consume the ready prefix IN ORDER so the sum keeps CRS order.
-                while (k < e) {
-                    unsigned long long bits[kBatch];
+                bool publish = false;
+                unsigned long long out = kCanonNaN;
+                if (ready == in_batch) { // batch consumed
+                    k += in_batch;
+                    if (k == e) {
+                        const double v = (rhs - acc) / d;
+                        out = (unsigned long long)__double_as_longlong(v);
+                        if (v != v) out = kCanonNaN; // never publish the sentinel pattern
+                        publish = true;
+                        in_batch = ready = 0;
+                    } else {
+                        in_batch = e - k < (int64_t)kBatch ? (int)(e - k) : kBatch;
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) {
+                            pc[j] = j < in_batch ? dep[k + j] : 0;
+                            av[j] = j < in_batch ? val[k + j] : 0.0; // does not wait for the dependency
+                        }
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j)
+                            bits[j] = j < in_batch ? __hip_atomic_load(&xs[pc[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                   : 0ull;
+                        ready = 0;
+                    }
+                } else { // poll again exactly the words of this batch that were still pending
 #pragma unroll
                     for (int j = 0; j < kBatch; ++j)
-                        bits[j] = (k + j < e) ? __hip_atomic_load(&xs[col[k + j]], __ATOMIC_RELAXED,
-                                                                  __HIP_MEMORY_SCOPE_AGENT)
-                                              : 0ull;
-                    int ready = 0;
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) {
-                        if (ready == j && k + j < e && bits[j] != kSentinel) {
-                            acc = fma(val[k + j], __longlong_as_double((long long)bits[j]), acc);
-                            ready = j + 1;
-                        }
-                    }
-                    k += ready;
-                    if (ready < kBatch) break; // hit a pending dependency (or the row end)
+                        if (j >= ready && j < in_batch && bits[j] == kSentinel)
+                            bits[j] = __hip_atomic_load(&xs[pc[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (k == e) {
-                    const double v = (rhs - acc) / d;
-                    unsigned long long out = (unsigned long long)__double_as_longlong(v);
-                    if (v != v) out = kCanonNaN; // never publish the sentinel pattern
-                    __hip_atomic_store(&xs[r], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    x[r] = __longlong_as_double((long long)out);
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    if (ready == j && j < in_batch && bits[j] != kSentinel) {
+                        acc = fma(av[j], __longlong_as_double((long long)bits[j]), acc);
+                        ready = j + 1;
+                    }
+                }
+                if (ready < in_batch) { // still pending
+                    if (++spins > kSpinLimit) publish = true; // bounded: a lost hand-off must not hang the GPU (publishes NaN)
+                    else __builtin_amdgcn_s_sleep(1);
+                }
+                {
+                    // The publishing store is predicated INSIDE one volatile asm, with no branch
+                    // the compiler can see.  Written as `if (publish) store` the optimiser
+                    // (legally, for one thread) turns the wait loop into
+                    // "do { poll } while (!publish); store": the store then runs only after
+                    // EVERY lane of the wave is ready to publish, and lanes of one wave that
+                    // depend on each other wait forever (observed: ROCm 7.2, both with a plain
+                    // agent-scope atomic store and with an asm store inside the if).
+                    unsigned long long *dst = &xs[slot];
+                    const unsigned pflag = publish ? 1u : 0u;
+                    unsigned long long saved_exec;
+                    if (ONE_XCD)
+                        asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %0, vcc\n\t"
+                                     "global_store_dwordx2 %1, %2, off\n\ts_mov_b64 exec, %0"
+                                     : "=&s"(saved_exec) : "v"(dst), "v"(out), "v"(pflag) : "vcc", "memory");
+                    else
+                        asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %0, vcc\n\t"
+                                     "global_store_dwordx2 %1, %2, off sc1\n\ts_mov_b64 exec, %0"
+                                     : "=&s"(saved_exec) : "v"(dst), "v"(out), "v"(pflag) : "vcc", "memory");
+                }
+                if (publish) {
+                    x[r] = __longlong_as_double((long long)out); // nobody polls x: may sink out of the loop
                     done = true;
-                } else {
-                    __builtin_amdgcn_s_sleep(1);
                 }
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void invert_perm_kernel(const int32_t *__restrict__ perm, int64_t n,
+                                                          int32_t *__restrict__ inv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) inv[perm[i]] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void cols_to_positions_kernel(const int32_t *__restrict__ col,
+                                                                const int32_t *__restrict__ inv,
+                                                                int64_t nnz, int32_t *__restrict__ pcol) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += stride) pcol[k] = inv[col[k]];
 }
 
 
@@ -281,7 +368,8 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,
                        (unsigned long long *)p->xs, n);
-    BIS_HIP_CHECK(ctx, hipMemsetAsync(p->ticket, 0, sizeof(unsigned), ctx->stream));
+    static const unsigned tk[2] = {0u, 0xffffffffu}; // ticket counter, elected XCD (none yet)
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(p->ticket, tk, sizeof tk, hipMemcpyHostToDevice, ctx->stream));
     // persistent grid: resident by construction (<= 8 workgroups of 256 per CU, 51 VGPRs)
     const int64_t n_tickets = (n + kTrsvT - 1) / kTrsvT;
     // Only ~one level is runnable at a time: keep a few of the widest levels
@@ -289,18 +377,56 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     // (measured: HPCG-128 4.6 ms at 64-128 workgroups, 9.3 ms at 512, 22 ms at
     // 1024; Anderson-256 4.5 ms at 256, 13.5 ms at 1024).
     int64_t want = (4 * p->max_level_width + kTrsvT - 1) / kTrsvT + 1;
-    want = std::min<int64_t>(want, ctx->n_cus);
+    const int one_xcd = bis_opts().trsv_one_xcd < 0 ? 0 : bis_opts().trsv_one_xcd;
+    if (one_xcd) want = std::min<int64_t>(want, (int64_t)(ctx->n_cus / 8) * one_xcd) * 8; // per XCD x 8 XCDs
+    else want = std::min<int64_t>(want, ctx->n_cus);
     if (bis_opts().trsv_grid > 0) want = bis_opts().trsv_grid;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_tickets, want),
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(one_xcd ? n_tickets * 8 : n_tickets, want),
                                                                  (int64_t)ctx->n_cus * 8));
-    if (T->rp64)
-        hipLaunchKernelGGL(sptrsv_syncfree_kernel<int64_t>, dim3(grid), dim3(kTrsvT), 0, ctx->stream,
-                           (const int64_t *)T->row_ptr, T->col, T->val, p->perm, n, D, b, x,
-                           (unsigned long long *)p->xs, p->ticket);
-    else
-        hipLaunchKernelGGL(sptrsv_syncfree_kernel<int32_t>, dim3(grid), dim3(kTrsvT), 0, ctx->stream,
-                           (const int32_t *)T->row_ptr, T->col, T->val, p->perm, n, D, b, x,
-                           (unsigned long long *)p->xs, p->ticket);
+    // dependencies loaded per round trip: the whole row when it fits (HPCG-128 U, 13 per row: 3.05 ms with 16,
+    // 5.28 ms with 8; Anderson-256, 3 per row: 2.4 ms with 4 or 8)
+    const int batch = bis_opts().trsv_batch > 0 ? bis_opts().trsv_batch : (T->max_row_nnz > 8 ? 16 : T->max_row_nnz > 4 ? 8 : 4);
+    // The scratch vector lives in LEVEL order (position in perm), so the polls and the
+    // stores of neighbouring lanes fall into the same cache lines; pcol = positions
+    // of the columns, built at the first solve.
+    const int by_pos = bis_opts().trsv_by_pos < 0 ? 1 : bis_opts().trsv_by_pos;
+    if (by_pos && !p->pcol && !p->no_pos && T->nnz > 0) {
+        int32_t *inv = nullptr;
+        BIS_HIP_CHECK(ctx, hipMalloc(&inv, sizeof(int32_t) * (size_t)n));
+        hipError_t pe = hipMalloc(&p->pcol, sizeof(int32_t) * (size_t)T->nnz);
+        if (pe != hipSuccess) { hipFree(inv); p->pcol = nullptr; ctx->err = "sptrsv: out of memory for the position table"; return BIS_ERR_HIP; }
+        hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           p->perm, n, inv);
+        // the view's first non-zero: row views share the parent's arrays
+        int64_t k0 = 0;
+        { int64_t a64 = 0; int32_t a32 = 0;
+          BIS_HIP_CHECK(ctx, hipMemcpyAsync(T->rp64 ? (void *)&a64 : (void *)&a32, T->row_ptr, T->rp64 ? 8 : 4, hipMemcpyDeviceToHost, ctx->stream));
+          BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+          k0 = T->rp64 ? a64 : a32; }
+        if (k0 != 0) { // a row view (absolute indices into the parent's arrays): keep the row-order scratch
+            hipFree(p->pcol); p->pcol = nullptr; p->no_pos = true;
+        } else
+        hipLaunchKernelGGL(cols_to_positions_kernel, dim3((unsigned)std::min<int64_t>((T->nnz + 255) / 256, 8192)), dim3(256), 0,
+                           ctx->stream, T->col, inv, T->nnz, p->pcol);
+        BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(inv);
+    }
+    const int32_t *dep = (by_pos && p->pcol) ? p->pcol : T->col;
+    const int pos_flag = (by_pos && p->pcol) ? 1 : 0;
+#define BIS_TRSV_LAUNCH(RP, ONE, B)                                                                    \
+    hipLaunchKernelGGL((sptrsv_syncfree_kernel<RP, ONE, B>), dim3(grid), dim3(kTrsvT), 0, ctx->stream, \
+                       (const RP *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,                      \
+                       (unsigned long long *)p->xs, p->ticket, pos_flag)
+#define BIS_TRSV_B(RP, ONE)                                                                            \
+    do {                                                                                               \
+        if (batch >= 16) BIS_TRSV_LAUNCH(RP, ONE, 16);                                                 \
+        else if (batch >= 8) BIS_TRSV_LAUNCH(RP, ONE, 8);                                              \
+        else BIS_TRSV_LAUNCH(RP, ONE, 4);                                                              \
+    } while (0)
+    if (T->rp64) { if (one_xcd) BIS_TRSV_B(int64_t, true); else BIS_TRSV_B(int64_t, false); }
+    else { if (one_xcd) BIS_TRSV_B(int32_t, true); else BIS_TRSV_B(int32_t, false); }
+#undef BIS_TRSV_B
+#undef BIS_TRSV_LAUNCH
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
 }

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Time bis_sptrsv / bis_bsptrsv (natural order, sync-free kernel) for several option sets in one process.
+   python tools/trsv_ab.py hpcg 128 "one_xcd=0" "one_xcd=1" "one_xcd=2,grid=64" """
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from basic_iterative_solvers_amd import Context, load_library
+import numpy as np
+kind, n1 = sys.argv[1], int(sys.argv[2])
+cfgs = [dict(kv.split("=") for kv in c.split(",")) for c in sys.argv[3:]]
+lib = load_library()
+ctx = Context(0)
+A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_anderson(n1, shift=9.0)
+Ls, Us, D, Dinv = ctx.split_strict(A)
+N = A.n_rows
+b, x, ref = ctx.alloc(N), ctx.alloc(N), None
+b.set(np.random.default_rng(1).uniform(-1, 1, N))
+for c in cfgs:
+    lib.bis_set_option(b"trsv_one_xcd", int(c.get("one_xcd", -1)))
+    lib.bis_set_option(b"trsv_grid", int(c.get("grid", -1)))
+    lib.bis_set_option(b"trsv_batch", int(c.get("batch", -1)))
+    lib.bis_set_option(b"trsv_by_pos", int(c.get("pos", -1)))
+    ctx.sptrsv(Ls, x, D, b); ctx.sync()
+    got = x.to_host()
+    if ref is None: ref = got
+    same = bool(np.array_equal(got, ref))
+    ts = []
+    for solve, T in ((ctx.sptrsv, Ls), (ctx.bsptrsv, Us)):
+        solve(T, x, D, b); ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(5): solve(T, x, D, b)
+        ctx.sync(); ts.append((time.perf_counter() - t0) / 5 * 1e3)
+    print(f"{kind}-{n1} {c}: forward {ts[0]:.3f} ms  backward {ts[1]:.3f} ms  bit-identical to first config: {same}", flush=True)
