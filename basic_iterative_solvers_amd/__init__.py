@@ -121,6 +121,15 @@ class Context:
                                                  _i64(row0), _i64(row1), C.byref(h)))
         return Mat(self, h)
 
+    def gen_fem(self, nx, ny=None, nz=None, keep=85, seed=1, row0=0, row1=None):
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        row1 = 3 * nx * ny * nz if row1 is None else row1
+        h = C.c_void_p()
+        self.check(self.lib.bis_mat_gen_fem(self.h, _i64(nx), _i64(ny), _i64(nz), C.c_int(keep),
+                                            C.c_uint64(seed), _i64(row0), _i64(row1), C.byref(h)))
+        return Mat(self, h)
+
     def split_strict(self, A):
         n = A.n_rows
         D, Dinv = self.alloc(n), self.alloc(n)

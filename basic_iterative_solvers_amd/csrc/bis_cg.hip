@@ -314,6 +314,8 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
     const size_t nblk = cg->dist ? (size_t)bis_dist_total_blocks(cg->dist) : (size_t)cg->A->n_blocks_f;
     bis_status st = bis_ensure_partials(ctx, std::max((size_t)2 * kMaxReduceBlocks, nblk * 16)); // <= 16 waves per row block
     if (st != BIS_OK) return st;
+    ctx->spmv_stop = cg->flags;
+    struct StopGuard { bis_ctx *c; ~StopGuard() { c->spmv_stop = nullptr; } } stop_guard{ctx};
     for (int it = 0; it < n_iters; ++it) {
         int n_part = 0;
         if (cg->dist) st = bis_dist_spmv_launch(ctx, cg->dist, cg->p, cg->tmp, cg->p, &n_part);

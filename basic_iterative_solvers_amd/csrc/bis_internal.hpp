@@ -42,6 +42,10 @@ struct bis_ctx {
 
     std::map<std::string, bis_named_kernel> kernels; // named-kernel registry (SMAX protocol)
 
+    // set by bis_cg_iterate around its launches: the fused-dot SpMV returns at once when
+    // flags[1] (the solver's stop flag) is set, like the other passes of a stopped iteration
+    const int *spmv_stop = nullptr;
+
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -145,6 +145,84 @@ __global__ void gen_anderson_kernel(int64_t L, double t, double W, double shift,
     for (int k = 0; k < 7; ++k) { col[p + k] = (int32_t)c[k]; val[p + k] = v[k]; }
 }
 
+// ---- FEM-like unstructured generator (stand-in for SuiteSparse Flan_1565) ----
+// nx*ny*nz nodes, 3 unknowns per node; node a couples (full 3x3 blocks) to itself and
+// to each in-grid 27-point neighbour b that survives a symmetric coin flip; symmetric
+// negative off-diagonals, a_rr = 1 + sum |a_rc| accumulated left to right (SPD).
+// Same formulas, same summation order as oracle/bis_oracle.c orc_gen_fem.
+constexpr uint64_t kFemK1 = 0x5851F42D4C957F2Dull, kFemK2 = 0x14057B7EF767814Full;
+
+// one row: returns its length; writes columns/values when col != nullptr
+__device__ inline int fem_row(int64_t nx, int64_t ny, int64_t nz, int keep, uint64_t seed, int64_t row,
+                              int32_t *col, double *val) {
+    const int64_t n_nodes = nx * ny * nz, n_rows = 3 * n_nodes;
+    const int64_t a = row / 3;
+    const int64_t i = a % nx, j = (a / nx) % ny, k = a / (nx * ny);
+    int len = 0, dpos = -1;
+    double acc = 0.0;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int64_t ii = i + dx, jj = j + dy, kk = k + dz;
+                if (ii < 0 || ii >= nx || jj < 0 || jj >= ny || kk < 0 || kk >= nz) continue;
+                const int64_t b = ii + nx * (jj + ny * kk);
+                if (b != a) {
+                    const int64_t lo = a < b ? a : b, hi = a < b ? b : a;
+                    if (!(anderson_u01(seed ^ kFemK1, (uint64_t)(lo * n_nodes + hi)) * 100.0 < (double)keep)) continue;
+                }
+                for (int d = 0; d < 3; ++d) {
+                    const int64_t c = 3 * b + d;
+                    if (col) {
+                        col[len] = (int32_t)c;
+                        if (c == row) { dpos = len; val[len] = 0.0; }
+                        else {
+                            const int64_t lo = row < c ? row : c, hi = row < c ? c : row;
+                            const double v = -(0.05 + 0.95 * anderson_u01(seed ^ kFemK2, (uint64_t)(lo * n_rows + hi)));
+                            val[len] = v;
+                            acc += fabs(v);
+                        }
+                    }
+                    ++len;
+                }
+            }
+    if (col) val[dpos] = 1.0 + acc;
+    return len;
+}
+
+__global__ __launch_bounds__(256) void fem_count_kernel(int64_t nx, int64_t ny, int64_t nz, int keep,
+                                                        uint64_t seed, int64_t row0, int64_t n_local,
+                                                        int64_t *blk) {
+    __shared__ double lds[4];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int len = r < n_local ? fem_row(nx, ny, nz, keep, seed, row0 + r, nullptr, nullptr) : 0;
+    const double tot = block_sum<256>((double)len, lds);
+    if (threadIdx.x == 0) blk[blockIdx.x] = (int64_t)tot;
+}
+
+template <typename RP>
+__global__ __launch_bounds__(256) void fem_fill_kernel(int64_t nx, int64_t ny, int64_t nz, int keep,
+                                                       uint64_t seed, int64_t row0, int64_t n_local,
+                                                       const int64_t *blk, RP *row_ptr, int32_t *col,
+                                                       double *val) {
+    __shared__ int64_t sc[256];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int len = r < n_local ? fem_row(nx, ny, nz, keep, seed, row0 + r, nullptr, nullptr) : 0;
+    sc[threadIdx.x] = len;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int64_t a = 0;
+        if ((int)threadIdx.x >= off) a = sc[threadIdx.x - off];
+        __syncthreads();
+        sc[threadIdx.x] += a;
+        __syncthreads();
+    }
+    if (r >= n_local) return;
+    const int64_t p = blk[blockIdx.x] + sc[threadIdx.x] - len;
+    row_ptr[r] = (RP)p;
+    if (r == n_local - 1) row_ptr[n_local] = (RP)(p + len);
+    fem_row(nx, ny, nz, keep, seed, row0 + r, col + p, val + p);
+}
+
 // ---- strict split ---------------------------------------------------------------
 constexpr int kSplitT = 256;
 
@@ -539,6 +617,53 @@ bis_status bis_mat_gen_anderson(bis_ctx *ctx, int64_t L, double t, double W, dou
         hipLaunchKernelGGL(gen_anderson_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, L, t,
                            W, shift, seed, row0, row1, (int32_t *)A->row_ptr, A->col, A->val);
     if (hipGetLastError() != hipSuccess) { bis_mat_destroy(ctx, A); ctx->err = "gen_anderson launch failed"; return BIS_ERR_HIP; }
+    st = bis_mat_finalize(ctx, A);
+    if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
+    *out = A;
+    return BIS_OK;
+}
+
+bis_status bis_mat_gen_fem(bis_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int keep_percent,
+                           uint64_t seed, int64_t row0, int64_t row1, bis_mat **out) {
+    BIS_CTX_OK(ctx);
+    const int64_t N = 3 * nx * ny * nz;
+    BIS_REQUIRE(ctx, out && nx >= 1 && ny >= 1 && nz >= 1 && N < INT32_MAX && keep_percent >= 0 &&
+                         keep_percent <= 100 && row0 >= 0 && row0 <= row1 && row1 <= N,
+                "bis_mat_gen_fem: bad arguments");
+    const int64_t n_local = row1 - row0;
+    const int n_blk = (int)((n_local + 255) / 256);
+    int64_t *blk = nullptr;
+    BIS_HIP_CHECK(ctx, hipMalloc(&blk, sizeof(int64_t) * (size_t)(2 * n_blk + 4)));
+    int64_t *dummy = blk + n_blk, *tot = blk + 2 * n_blk;
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(blk, 0, sizeof(int64_t) * (size_t)(2 * n_blk + 4), ctx->stream));
+    if (n_blk > 0) {
+        hipLaunchKernelGGL(fem_count_kernel, dim3(n_blk), dim3(256), 0, ctx->stream, nx, ny, nz, keep_percent,
+                           seed, row0, n_local, blk);
+        hipLaunchKernelGGL(split_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, blk, dummy, n_blk, tot);
+    }
+    int64_t h_tot[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(h_tot, tot, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { hipFree(blk); ctx->err = "bis_mat_gen_fem: count pass failed"; return BIS_ERR_HIP; }
+    const int64_t nnz = h_tot[0];
+    const bool rp64 = nnz >= (int64_t)INT32_MAX - kPad;
+    bis_mat *A = nullptr;
+    bis_status st = bis_mat_alloc(ctx, n_local, N, nnz, rp64, &A);
+    if (st != BIS_OK) { hipFree(blk); return st; }
+    if (n_blk > 0) {
+        if (rp64)
+            hipLaunchKernelGGL(fem_fill_kernel<int64_t>, dim3(n_blk), dim3(256), 0, ctx->stream, nx, ny, nz,
+                               keep_percent, seed, row0, n_local, blk, (int64_t *)A->row_ptr, A->col, A->val);
+        else
+            hipLaunchKernelGGL(fem_fill_kernel<int32_t>, dim3(n_blk), dim3(256), 0, ctx->stream, nx, ny, nz,
+                               keep_percent, seed, row0, n_local, blk, (int32_t *)A->row_ptr, A->col, A->val);
+    } else {
+        hipMemsetAsync(A->row_ptr, 0, rp64 ? 8 : 4, ctx->stream);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(blk);
+    if (e != hipSuccess) { bis_mat_destroy(ctx, A); ctx->err = "gen_fem launch failed"; return BIS_ERR_HIP; }
     st = bis_mat_finalize(ctx, A);
     if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
     *out = A;

@@ -80,8 +80,9 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     const double *__restrict__ val, const double *x, double *y,
     const int32_t *__restrict__ blk_row, const int64_t *__restrict__ blk_nnz, int n_blocks,
     int n_blocks_pad8, const double *w, double *partials, const uint16_t *__restrict__ pk,
-    int64_t pk_base, const int32_t *__restrict__ seg_base, int col_max) {
+    int64_t pk_base, const int32_t *__restrict__ seg_base, int col_max, const int *stop) {
     constexpr bool FUSE_DOT = MODE == 1;
+    if (MODE == 1 && stop && stop[1]) return; // the solver has stopped: this iteration is a no-op
     extern __shared__ __attribute__((aligned(16))) double prod[];
     const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8)
                                     : (n_blocks_pad8 < -1 ? xcd_group_remap(blockIdx.x, -n_blocks_pad8) : (int)blockIdx.x);
@@ -470,6 +471,7 @@ struct SpmvArgs {
     size_t lds_bytes; hipStream_t stream; int mode; int n_cus = 256; bool remap = false; int remap_arg = -1; int grid = 0;
     const uint16_t *pk = nullptr; int64_t pk_base = 0; const int32_t *seg_base = nullptr; int col_max = 0; int pk_mode = 0;
     bool wide = false; // 2^29 columns or more: 64-bit x addressing, 32-bit column stream
+    const int *stop = nullptr;
 };
 
 template <typename RP, int T, int U, int BR = 0>
@@ -477,7 +479,7 @@ void launch_variant(const SpmvArgs &a) {
 #define BIS_LV(PK, MODE)                                                                          \
     hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, (PK) < 0 ? 0 : (PK), MODE, (PK) < 0, BR>), dim3(a.grid), dim3(T), a.lds_bytes, \
                        a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y, a.blk_row, a.blk_nnz, \
-                       a.nb, a.remap_arg, a.w, a.partials, a.pk, a.pk_base, a.seg_base, a.col_max)
+                       a.nb, a.remap_arg, a.w, a.partials, a.pk, a.pk_base, a.seg_base, a.col_max, a.stop)
 #define BIS_LVM(PK)                                                                               \
     do {                                                                                          \
         if (a.mode == 2) BIS_LV(PK, 2);                                                           \
@@ -693,6 +695,7 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     a.remap_arg = remap_arg_for(nb8);
     a.grid = grid_for_map(nb, a.remap_arg);
     if (bis_status st = ensure_packed(ctx, A, use_f ? 1 : 0, &a)) return st;
+    a.stop = w ? ctx->spmv_stop : nullptr;
     if (bis_opts().spmv_lds_pad > 0) a.lds_bytes += (size_t)bis_opts().spmv_lds_pad;
     bis_prof_begin(ctx);
     const bool ok = A->rp64 ? launch_by_id<int64_t>(spmv_variant(a), a)

@@ -419,7 +419,8 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
                        (unsigned long long *)p->xs, p->ticket, pos_flag)
 #define BIS_TRSV_B(RP, ONE)                                                                            \
     do {                                                                                               \
-        if (batch >= 16) BIS_TRSV_LAUNCH(RP, ONE, 16);                                                 \
+        if (batch >= 32) BIS_TRSV_LAUNCH(RP, ONE, 32);                                                 \
+        else if (batch >= 16) BIS_TRSV_LAUNCH(RP, ONE, 16);                                            \
         else if (batch >= 8) BIS_TRSV_LAUNCH(RP, ONE, 8);                                              \
         else BIS_TRSV_LAUNCH(RP, ONE, 4);                                                              \
     } while (0)

@@ -70,11 +70,18 @@ class ConjugateGradientSolver : public Solver {
             // enqueue a batch, then read the device-side history; the device stops
             // updating at the reference's stopping iteration (bis_cg.hip)
             if (fused_hist.empty()) {
-                const int batch = max_iters;
-                TIME(timers, "spmv", bis::check(bis_cg_iterate(bis::ctx(), fcg, batch), "bis_cg_iterate"))
-                fused_hist.resize(batch + 1);
-                int it = 0, conv = 0;
-                bis::check(bis_cg_status(bis::ctx(), fcg, &it, &conv, fused_hist.data(), batch + 1), "bis_cg_status");
+                // chunks of 50 iterations with a status read in between: passes enqueued
+                // behind the stopping iteration are no-ops, but they are still launches
+                int it = 0, conv = 0, enq = 0;
+                fused_hist.assign(1, 0.0);
+                while (enq < max_iters) {
+                    const int batch = std::min(50, max_iters - enq);
+                    TIME(timers, "spmv", bis::check(bis_cg_iterate(bis::ctx(), fcg, batch), "bis_cg_iterate"))
+                    enq += batch;
+                    fused_hist.resize(enq + 1);
+                    bis::check(bis_cg_status(bis::ctx(), fcg, &it, &conv, fused_hist.data(), enq + 1), "bis_cg_status");
+                    if (it < enq) break; // the device stopped inside this chunk
+                }
                 fused_hist.resize(it + 1);
             }
             return;

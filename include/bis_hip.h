@@ -138,6 +138,15 @@ BIS_API bis_status bis_mat_gen_anderson(bis_ctx *ctx, int64_t L, double t,
                                         int64_t row0, int64_t row1,
                                         bis_mat **out);
 
+/* FEM-like unstructured input (stands in for reading
+ * SuiteSparse Flan_1565.mtx in config 5): nx*ny*nz nodes with 3 unknowns each,
+ * 3x3-block couplings to the 27-point neighbours that survive a symmetric coin
+ * flip (keep_percent), symmetric negative off-diagonals, strictly dominant
+ * diagonal (SPD); ~3*(1+26*keep/100) non-zeros per interior row. */
+BIS_API bis_status bis_mat_gen_fem(bis_ctx *ctx, int64_t nx, int64_t ny,
+                                   int64_t nz, int keep_percent, uint64_t seed,
+                                   int64_t row0, int64_t row1, bis_mat **out);
+
 /* Setup steps kept on the device:
  * split_LU (utilities/LU_factors.hpp:122-309): strict lower / strict upper
  * parts of A, row order preserved; and the diagonal extraction of

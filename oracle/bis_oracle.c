@@ -614,6 +614,70 @@ ORC_API double orc_anderson_diag(uint64_t seed, uint64_t i, double W,
     return fma(W, anderson_u01(seed, i) - 0.5, shift);
 }
 
+/* FEM-like unstructured stand-in for SuiteSparse Flan_1565 (SURVEY.md section 8d-3;
+ * the .mtx itself is not fetchable): nx*ny*nz nodes, 3 unknowns per node, row =
+ * 3*node + d.  Node a couples to itself and to each in-grid neighbour b of its
+ * 27-point neighbourhood that survives a symmetric coin flip
+ * u01(seed^K1, min*n_nodes+max)*100 < keep; a coupling is a full 3x3 block.
+ * Off-diagonal a_rc = -(0.05 + 0.95*u01(seed^K2, min(r,c)*n_rows + max(r,c)))
+ * (symmetric); a_rr = 1 + sum_c |a_rc| accumulated left to right in column
+ * order (strictly diagonally dominant => SPD).  Ascending columns; about
+ * 3*(1 + 26*keep/100) non-zeros per interior row (keep = 85: ~69). */
+#define FEM_K1 0x5851F42D4C957F2Dull
+#define FEM_K2 0x14057B7EF767814Full
+static inline int fem_kept(uint64_t seed, int64_t a, int64_t b, int64_t n_nodes, int keep) {
+    const int64_t lo = a < b ? a : b, hi = a < b ? b : a;
+    return anderson_u01(seed ^ FEM_K1, (uint64_t)(lo * n_nodes + hi)) * 100.0 < (double)keep;
+}
+static inline double fem_offdiag(uint64_t seed, int64_t r, int64_t c, int64_t n_rows) {
+    const int64_t lo = r < c ? r : c, hi = r < c ? c : r;
+    return -(0.05 + 0.95 * anderson_u01(seed ^ FEM_K2, (uint64_t)(lo * n_rows + hi)));
+}
+/* one row: returns its length; writes columns/values when col != NULL */
+static int64_t fem_row(int64_t nx, int64_t ny, int64_t nz, int keep, uint64_t seed, int64_t row,
+                       int32_t *col, double *val) {
+    const int64_t n_nodes = nx * ny * nz, n_rows = 3 * n_nodes;
+    const int64_t a = row / 3;
+    const int64_t i = a % nx, j = (a / nx) % ny, k = a / (nx * ny);
+    int64_t len = 0, dpos = -1;
+    double acc = 0.0;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int64_t ii = i + dx, jj = j + dy, kk = k + dz;
+                if (ii < 0 || ii >= nx || jj < 0 || jj >= ny || kk < 0 || kk >= nz) continue;
+                const int64_t b = ii + nx * (jj + ny * kk);
+                if (b != a && !fem_kept(seed, a, b, n_nodes, keep)) continue;
+                for (int d = 0; d < 3; ++d) {
+                    const int64_t c = 3 * b + d;
+                    if (col) {
+                        col[len] = (int32_t)c;
+                        if (c == row) { dpos = len; val[len] = 0.0; }
+                        else { const double v = fem_offdiag(seed, row, c, n_rows); val[len] = v; acc += fabs(v); }
+                    }
+                    ++len;
+                }
+            }
+    if (col) val[dpos] = 1.0 + acc;
+    return len;
+}
+/* rows [row0,row1): pass 1 (col == NULL) fills row_ptr[0..n] (local offsets) and
+ * returns nnz; pass 2 fills col/val at those offsets. */
+ORC_API int64_t orc_gen_fem(int64_t nx, int64_t ny, int64_t nz, int keep, uint64_t seed, int64_t row0,
+                            int64_t row1, int64_t *row_ptr, int32_t *col, double *val) {
+    const int64_t n = row1 - row0;
+    if (!col) {
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < n; ++r) row_ptr[r + 1] = fem_row(nx, ny, nz, keep, seed, row0 + r, NULL, NULL);
+        row_ptr[0] = 0;
+        for (int64_t r = 0; r < n; ++r) row_ptr[r + 1] += row_ptr[r];
+        return row_ptr[n];
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) fem_row(nx, ny, nz, keep, seed, row0 + r, col + row_ptr[r], val + row_ptr[r]);
+    return row_ptr[n];
+}
+
 /* Anderson-L: 7-point, periodic L^3 grid (L >= 3), off-diagonals -t,
  * diagonal W*(u-1/2)+shift with u = u01(seed,row); ascending columns; exactly
  * 7 nnz per row.  Generates rows [row0,row1), global columns. */

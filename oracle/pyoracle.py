@@ -305,6 +305,22 @@ class Oracle:
                                   col.ctypes, val.ctypes)
         return CRS(n, rp, col, val, n_cols=N)
 
+    def gen_fem(self, nx, ny=None, nz=None, keep=85, seed=1, row0=0, row1=None):
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        N = 3 * nx * ny * nz
+        row1 = N if row1 is None else row1
+        n = row1 - row0
+        rp = np.zeros(n + 1, dtype=np.int64)
+        self.lib.orc_gen_fem.restype = C.c_int64
+        args = (C.c_int64(nx), C.c_int64(ny), C.c_int64(nz), C.c_int(keep), C.c_uint64(seed),
+                C.c_int64(row0), C.c_int64(row1))
+        nnz = self.lib.orc_gen_fem(*args, rp.ctypes, None, None)
+        col = np.zeros(nnz, dtype=np.int32)
+        val = np.zeros(nnz)
+        self.lib.orc_gen_fem(*args, rp.ctypes, col.ctypes, val.ctypes)
+        return CRS(n, rp, col, val, n_cols=N)
+
     def cg_run(self, A, iters, A_D=None, b_val=1.0, x0_val=0.1):
         """Plain CG loop for bench.py's cpu_baseline; returns (hist, seconds)."""
         hist = np.zeros(iters + 1)

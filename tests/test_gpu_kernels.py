@@ -140,6 +140,50 @@ def test_anderson_generator_bit_exact(ctx, oracle, L, shift):
         d.free()
 
 
+@pytest.mark.parametrize("shape,keep,rows", [((6, 5, 4), 85, None), ((3, 3, 3), 100, None), ((5, 4, 7), 60, (37, 301)),
+                                             ((1, 1, 1), 85, None), ((9, 1, 2), 0, None)])
+def test_fem_generator_bit_exact(ctx, oracle, shape, keep, rows):
+    """Config-5 stand-in (FEM-like, 3 unknowns per node, ragged rows): the device
+    generator reproduces the oracle's CRS bit for bit, also for a row range."""
+    N = 3 * shape[0] * shape[1] * shape[2]
+    row0, row1 = rows if rows else (0, N)
+    ref = oracle.gen_fem(*shape, keep=keep, seed=7, row0=row0, row1=row1)
+    d = ctx.gen_fem(*shape, keep=keep, seed=7, row0=row0, row1=row1)
+    rp, col, val = d.download()
+    assert np.array_equal(rp, ref.row_ptr) and np.array_equal(col, ref.col)
+    assert np.array_equal(val, ref.val)
+    d.free()
+
+
+def test_fem_medium_kernels_and_ilu0_vs_oracle(ctx, oracle):
+    """SpMV, both triangular solves and the device ILU(0) on the ragged FEM-like
+    matrix (rows of 18..81 non-zeros, ~1400 dependency levels) against the oracle."""
+    shape = (14, 12, 10)
+    A = oracle.gen_fem(*shape)
+    n = A.n_rows
+    dA = ctx.gen_fem(*shape)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, n)
+    dx, dy = ctx.upload(x), ctx.alloc(n)
+    ctx.spmv(dA, dx, dy)
+    assert relerr(dy.to_host(), oracle.spmv(A, x)) <= KTOL
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    dLs, dUs, dD, dDinv = ctx.split_strict(dA)
+    ctx.sptrsv(dLs, dy, dD, dx)
+    assert np.array_equal(dy.to_host(), oracle.sptrsv(Ls, D, x))
+    ctx.bsptrsv(dUs, dy, dD, dx)
+    assert np.array_equal(dy.to_host(), oracle.sptrsv(Us, D, x, backward=True))
+    iLs, iL_D, iUs, iU_D = oracle.factor_ilu0(A)
+    fLs, fL_D, fUs, fU_D = ctx.ilu0(dA)
+    rp, col, val = fUs.download()
+    assert np.array_equal(rp, iUs.row_ptr) and np.array_equal(col, iUs.col)
+    assert relerr(val, iUs.val) <= KTOL
+    rp, col, val = fLs.download()
+    assert np.array_equal(col, iLs.col) and relerr(val, iLs.val) <= KTOL
+    assert relerr(fU_D.to_host(), iU_D) <= KTOL
+
+
 @pytest.mark.parametrize("name", GOLDEN_MATS)
 def test_split_strict_bit_exact(ctx, name):
     """Device split_LU/peel_diag (LU_factors.hpp:122-309, :827-869) vs the
@@ -415,6 +459,49 @@ def test_named_kernel_protocol(ctx, oracle):
         ctx.check(lib.bis_kernel_set_mat_upper_triang(ctx.h, nm, up))
         ctx.check(lib.bis_kernel_run(ctx.h, nm, C.c_int64(0), C.c_int64(0), C.c_int64(0)))
         assert np.array_equal(dx.to_host(), ref)
+
+
+def test_full_size_fem_config5_properties(ctx):
+    """BASELINE config 5 size (stand-in for Flan_1565: 80x80x81 nodes, 1.56 M rows,
+    ~1.0e8 non-zeros): symmetry of the operator; triangular solves of the device
+    ILU(0) inverted exactly by a product; and (L U)_ij == A_ij on A's pattern for
+    sampled rows (the defining property of ILU(0))."""
+    import scipy.sparse as sp
+    shape = (80, 80, 81)
+    dA = ctx.gen_fem(*shape)
+    N = dA.n_rows
+    assert N == 3 * 80 * 80 * 81 and 60 * N < dA.nnz < 81 * N
+    rng = np.random.default_rng(6)
+    u, v = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N)
+    du, dv, yu, yv = ctx.upload(u), ctx.upload(v), ctx.alloc(N), ctx.alloc(N)
+    ctx.spmv(dA, du, yu); ctx.spmv(dA, dv, yv)
+    a, b2 = ctx.dot(yu, dv), ctx.dot(du, yv)
+    assert abs(a - b2) <= 1e-12 * max(abs(a), abs(b2), 1.0)
+    fLs, fL_D, fUs, fU_D = ctx.ilu0(dA)
+    x, t = ctx.alloc(N), ctx.alloc(N)
+    for solve, T, D in ((ctx.sptrsv, fLs, fL_D), (ctx.bsptrsv, fUs, fU_D)):
+        solve(T, x, D, du)
+        ctx.spmv(T, x, t)                       # t = T x
+        ctx.elemwise_mult_vectors(yu, D, x)     # yu = D x
+        ctx.sum_vectors(t, t, yu)               # (D + T) x
+        ctx.subtract_vectors(t, t, du)
+        assert ctx.euclidean_vec_norm(t) <= 1e-12 * np.sqrt(N) * 20
+    rows = np.sort(rng.choice(N, 400, replace=False))
+    arp, acol, aval = dA.download()
+    lrp, lcol, lval = fLs.download()
+    urp, ucol, uval = fUs.download()
+    A = sp.csr_matrix((aval, acol, arp), shape=(N, N))
+    L = sp.csr_matrix((lval, lcol, lrp), shape=(N, N)) + sp.identity(N, format="csr")
+    U = sp.csr_matrix((uval, ucol, urp), shape=(N, N)) + sp.diags(fU_D.to_host(), format="csr")
+    P = (L[rows] @ U).tocsr()
+    Ar = A[rows].tocsr()
+    worst = 0.0
+    for i in range(len(rows)):
+        cols = Ar.indices[Ar.indptr[i]:Ar.indptr[i + 1]]
+        want = Ar.data[Ar.indptr[i]:Ar.indptr[i + 1]]
+        got = np.asarray(P[i, cols].todense()).ravel()
+        worst = max(worst, np.abs(got - want).max())
+    assert worst <= 1e-12
 
 
 def test_full_size_anderson256_properties(ctx):

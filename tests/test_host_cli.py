@@ -86,6 +86,23 @@ def test_cli_errors():
     assert out.returncode != 0 and "Not enough arguments" in out.stdout
 
 
+@pytest.mark.parametrize("solver,pc", [("bi", "ilu0"), ("cg", "j"), ("gm", "gs"), ("cg", "sgs"), ("gs", "none")])
+def test_cli_fem_generator_histories_vs_oracle(oracle, solver, pc):
+    """Config 5's input family (FEM-like unstructured generator, `fem:NX,NY,NZ`):
+    the CLI's residual table against the reference algorithm (oracle, real ILU(0))
+    on the oracle's own copy of the matrix."""
+    MATRIX_ARG["fem_6x5x4"] = "fem:6,5,4,seed=3"
+    kw = {"restart_len": 30} if solver == "gm" else {}
+    r = run_cli("fem_6x5x4", solver, pc, kw)
+    A = oracle.gen_fem(6, 5, 4, seed=3)
+    o = oracle.solve(A, solver, pc, ilu_real=True, **kw)
+    e = dict(hist=[float(v) for v in o["hist"]], iters=o["iters"], converged=o["converged"])
+    assert abs(r["hist"][0] - e["hist"][0]) <= 1e-13 * e["hist"][0]
+    check_history(r, e, solver)
+    if solver != "bi":
+        assert abs(r["iters"] - o["iters"]) <= 1
+
+
 @pytest.mark.parametrize("name,solver,pc", [("hpcg8", "gm", "gs"), ("hpcg8", "cg", "sgs"),
                                             ("anderson8_shift9", "bi", "ilu0"),
                                             ("anderson8_shift9", "gs", "none"),

@@ -175,3 +175,28 @@ def test_ref_unit_solvers_3x3(oracle, solver, pc):
     xs = np.linalg.solve(A.to_scipy().toarray(), np.ones(3))
     assert r["converged"]
     assert np.allclose(r["x"], xs, atol=1e-7)
+
+
+def test_fem_generator_properties(oracle):
+    """FEM-like stand-in for config 5 (oracle/bis_oracle.c orc_gen_fem): symmetric,
+    strictly diagonally dominant with positive diagonal (SPD), ascending columns,
+    ragged rows, and any row range equals the same rows of the full matrix."""
+    import scipy.sparse as sp
+    A = oracle.gen_fem(6, 5, 4, keep=85, seed=3)
+    n = A.n_rows
+    assert n == 3 * 6 * 5 * 4
+    M = sp.csr_matrix((A.val, A.col, A.row_ptr), shape=(n, n))
+    assert abs(M - M.T).max() == 0.0
+    d = M.diagonal()
+    off = np.asarray(abs(M).sum(axis=1)).ravel() - np.abs(d)
+    assert (d > 0).all() and (d - off > 0.999).all()
+    lens = np.diff(A.row_ptr)
+    assert lens.min() < lens.max() and lens.max() <= 81 and (lens % 3 == 0).all()
+    for r in range(n):
+        c = A.col[A.row_ptr[r]:A.row_ptr[r + 1]]
+        assert (np.diff(c) > 0).all()
+    B = oracle.gen_fem(6, 5, 4, keep=85, seed=3, row0=100, row1=200)
+    assert np.array_equal(B.col, A.col[A.row_ptr[100]:A.row_ptr[200]])
+    assert np.array_equal(B.val, A.val[A.row_ptr[100]:A.row_ptr[200]])
+    full = oracle.gen_fem(3, 3, 3, keep=100)
+    assert np.diff(full.row_ptr).max() == 81 and np.diff(full.row_ptr).min() == 24

@@ -10,7 +10,7 @@ kind, n1 = sys.argv[1], int(sys.argv[2])
 cfgs = [dict(kv.split("=") for kv in c.split(",")) for c in sys.argv[3:]]
 lib = load_library()
 ctx = Context(0)
-A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_anderson(n1, shift=9.0)
+A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_fem(n1) if kind == "fem" else ctx.gen_anderson(n1, shift=9.0)
 Ls, Us, D, Dinv = ctx.split_strict(A)
 N = A.n_rows
 b, x, ref = ctx.alloc(N), ctx.alloc(N), None
