@@ -10,9 +10,12 @@
 // Parallel form: row i needs the finished rows k < i of its pattern, i.e. the
 // dependency levels of A's strict lower triangle (the level-parallel variant
 // the reference keeps behind SMAX, LU_factors.hpp:541-768).  One launch per
-// level, one lane per row; rows of a level are independent.  The per-row
-// arithmetic is sequential and identical to the serial algorithm, so the
-// factors do not depend on the schedule.
+// level; rows of a level are independent.  One WAVE per row (row in LDS, the
+// updates of one elimination spread over the lanes; a lane-per-row kernel
+// remains for rows beyond the LDS budget).  Every entry sees the serial
+// algorithm's fma sequence, so the factors do not depend on the schedule.
+// Config-5 stand-in (1.54 M rows, 1.04e8 non-zeros, 1661 levels): 4.45 s with a
+// lane per row (35 x 35 x 7 dependent loads per row) -> see DESIGN.md.
 #include "bis_internal.hpp"
 
 #include <algorithm>
@@ -87,6 +90,73 @@ __global__ __launch_bounds__(256) void ilu0_level_kernel(const RP *__restrict__ 
     L_D[i] = 1.0;
 }
 
+// Wave-per-row form of the same elimination (rows of up to kIluMaxRow entries):
+// the row lives in LDS; the eliminations k stay sequential and ascending (the
+// reference's order), but the updates of one elimination -- one per entry of U's
+// row k -- run on the lanes of the wave, each lane locating its column in the LDS
+// copy by binary search.  Every entry receives the same fma sequence as in the
+// serial algorithm, so the factors are identical to the lane-per-row kernel's.
+constexpr int kIluMaxRow = 1024;
+
+template <typename RP>
+__global__ __launch_bounds__(256) void ilu0_level_wave_kernel(const RP *__restrict__ rp,
+                                                              const int32_t *__restrict__ wcol, double *wval,
+                                                              const int64_t *__restrict__ dpos,
+                                                              const int64_t *__restrict__ ustart,
+                                                              const int32_t *__restrict__ perm, int64_t begin,
+                                                              int64_t end, double pivot_tol, double pivot_repl,
+                                                              double *U_D, double *L_D, int max_row) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ilu_smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *lval = reinterpret_cast<double *>(ilu_smem) + (size_t)wave * max_row;
+    int32_t *lcol = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(ilu_smem) + (size_t)4 * max_row) +
+                    (size_t)wave * max_row;
+    const int64_t t = begin + (int64_t)blockIdx.x * 4 + wave;
+    if (t >= end) return; // whole wave
+    const int i = perm[t];
+    const int64_t s = rp[i], e = rp[i + 1];
+    const int len = (int)(e - s);
+    for (int q = lane; q < len; q += 64) { lcol[q] = wcol[s + q]; lval[q] = wval[s + q]; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int p = 0; p < len; ++p) {
+        const int k = lcol[p]; // uniform
+        if (k >= i) break;
+        const double pivot = U_D[k]; // row k finished in an earlier level
+        if (fabs(pivot) < 1e-16) continue;
+        const double factor = lval[p] / pivot; // every lane computes the same value
+        const int64_t us = ustart[k], ue = (int64_t)rp[k + 1];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all lanes have read lval[p] before it is overwritten
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) lval[p] = factor;
+        for (int64_t q = us + lane; q < ue; q += 64) {
+            const int j = wcol[q];
+            const double u = wval[q];
+            int lo = p + 1, hi = len; // j > k: search the rest of row i
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (lcol[mid] < j) lo = mid + 1; else hi = mid;
+            }
+            if (lo < len && lcol[lo] == j) {
+                const double w = lval[lo];
+                if (w != 0.0) lval[lo] = fma(-factor, u, w);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // updates visible to the next elimination
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int64_t dp = dpos[i];
+    double u_diag = dp >= 0 ? lval[dp - s] : 0.0;
+    if (fabs(u_diag) < pivot_tol) u_diag = (u_diag >= 0 ? 1.0 : -1.0) * pivot_repl;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && dp >= 0) lval[dp - s] = u_diag;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int q = lane; q < len; q += 64) wval[s + q] = lval[q];
+    if (lane == 0) { U_D[i] = u_diag; L_D[i] = 1.0; }
+}
+
 template <typename RP>
 bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot_repl, bis_mat **Ls_out,
                   bis_mat **Us_out, double *L_D, double *U_D) {
@@ -124,6 +194,12 @@ bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot
         const int nl = (int)level_ptr->size() - 1;
         for (int l = 0; l < nl; ++l) {
             const int64_t lo = (*level_ptr)[l], hi = (*level_ptr)[l + 1];
+            if (W->max_row_nnz <= kIluMaxRow && bis_opts().ilu0_wave != 0) {
+                const int mr = std::max(W->max_row_nnz, 1);
+                hipLaunchKernelGGL(ilu0_level_wave_kernel<RP>, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256),
+                                   (size_t)4 * mr * (sizeof(double) + sizeof(int32_t)), ctx->stream, rp, W->col,
+                                   W->val, dpos, ustart, perm, lo, hi, pivot_tol, pivot_repl, U_D, L_D, mr);
+            } else
             hipLaunchKernelGGL(ilu0_level_kernel<RP>, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0,
                                ctx->stream, rp, W->col, W->val, dpos, ustart, perm, lo, hi, pivot_tol,
                                pivot_repl, U_D, L_D);

@@ -60,6 +60,7 @@ struct bis_options {
     int spmv_chunk_fused = -1; // -1: default (2048) for the SpMV with the fused dot epilogue
     int spmv_xcd_remap = -1; // 1: each XCD sweeps its own slab of row blocks (default: blockIdx order)
     int trsv_grid = -1;    // -1: automatic
+    int ilu0_wave = -1;    // 0: lane-per-row ILU(0) level kernel (default: wave per row)
     int trsv_batch = -1;   // dependencies polled per round trip (4, 8, 16; -1: by row length)
     int trsv_by_pos = -1;  // 1 (default): sentinel scratch in level order; 0: in row order
     int trsv_one_xcd = -1; // k > 0: sync-free sweeps run on one elected XCD with k workgroups per CU
