@@ -130,6 +130,16 @@ class Context:
                                             C.c_uint64(seed), _i64(row0), _i64(row1), C.byref(h)))
         return Mat(self, h)
 
+    def multicolour(self, A):
+        """B = P A P^T grouped by colour; returns (B, perm[new]=old as numpy int32, n_colours)."""
+        n = A.n_rows
+        store = self.alloc((n + 1) // 2 + 1)
+        h, nc = C.c_void_p(), C.c_int()
+        self.check(self.lib.bis_mat_multicolour(self.h, A.h, C.byref(h), C.c_void_p(store.ptr), C.byref(nc)))
+        perm = store.to_host().view(np.int32)[:n].copy()
+        store.free()
+        return Mat(self, h), perm, nc.value
+
     def split_strict(self, A):
         n = A.n_rows
         D, Dinv = self.alloc(n), self.alloc(n)

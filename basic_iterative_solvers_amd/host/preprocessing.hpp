@@ -80,23 +80,49 @@ inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::u
     }
 
     if (cli_args->perm_mode == "mc") { // the SMAX permute_mat step (preprocessing.hpp:58-62)
-        download_to_host(solver->A.get());
-        std::vector<int> perm, inv_perm;
+        const int N = solver->A->n_rows;
         int n_colours = 0;
-        multicolour_permutation(solver->A.get(), perm, inv_perm, n_colours);
-        auto B = std::make_unique<MatrixCRS>();
-        permute_matrix(solver->A.get(), perm, inv_perm, B.get());
-        B->upload();
-        solver->A = std::move(B);
-        // x_0 is the constant INIT_X_VAL (invariant under P); b is constant too
-        // unless -scale has rescaled it: permute it through the host (setup only)
-        if (solver->num_scale) {
-            const int N = solver->A->n_rows;
-            std::vector<double> hb(N), pb(N);
-            to_host(hb.data(), solver->b, N);
-            for (int i = 0; i < N; ++i) pb[i] = hb[perm[i]];
-            to_device(solver->b, pb.data(), N);
+        std::vector<int> perm;
+        // device path: colouring, permutation and P A P^T stay in HBM
+        double *perm_store = nullptr;
+        bis::check(bis_vec_alloc(bis::ctx(), (N + 1) / 2 + 1, &perm_store), "bis_vec_alloc");
+        int32_t *perm_dev = reinterpret_cast<int32_t *>(perm_store);
+        bis_mat *Bm = nullptr;
+        const bis_status mc = cli_args->perm_host ? BIS_ERR_UNSUPPORTED
+                                                  : bis_mat_multicolour(bis::ctx(), solver->A->dev, &Bm, perm_dev, &n_colours);
+        if (mc == BIS_OK) {
+            auto B = std::make_unique<MatrixCRS>();
+            B->adopt(Bm);
+            solver->A = std::move(B);
+            if (solver->num_scale) { // b was rescaled row-wise: permute it (x_0 is constant)
+                double *pb = nullptr;
+                bis::check(bis_vec_alloc(bis::ctx(), N, &pb), "bis_vec_alloc");
+                bis::check(bis_vec_gather(bis::ctx(), pb, solver->b, perm_dev, N), "bis_vec_gather");
+                copy_vector(solver->b, pb, N);
+                bis::check(bis_vec_free(bis::ctx(), pb), "bis_vec_free");
+            }
+            if (!cli_args->dump_perm.empty()) {
+                std::vector<double> raw((N + 1) / 2 + 1);
+                to_host(raw.data(), perm_store, (N + 1) / 2 + 1);
+                const int32_t *pp = reinterpret_cast<const int32_t *>(raw.data());
+                perm.assign(pp, pp + N);
+            }
+        } else { // more than 64 colours (or -perm-host): the host version
+            download_to_host(solver->A.get());
+            std::vector<int> inv_perm;
+            multicolour_permutation(solver->A.get(), perm, inv_perm, n_colours);
+            auto B = std::make_unique<MatrixCRS>();
+            permute_matrix(solver->A.get(), perm, inv_perm, B.get());
+            B->upload();
+            solver->A = std::move(B);
+            if (solver->num_scale) {
+                std::vector<double> hb(N), pb(N);
+                to_host(hb.data(), solver->b, N);
+                for (int i = 0; i < N; ++i) pb[i] = hb[perm[i]];
+                to_device(solver->b, pb.data(), N);
+            }
         }
+        bis::check(bis_vec_free(bis::ctx(), perm_store), "bis_vec_free");
         if (!cli_args->dump_perm.empty()) write_permutation(cli_args->dump_perm, perm);
         std::cout << "multi-colour reordering: " << n_colours << " colours" << std::endl;
     } else if (cli_args->perm_mode != "none") {

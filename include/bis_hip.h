@@ -156,6 +156,19 @@ BIS_API bis_status bis_mat_split_strict(bis_ctx *ctx, const bis_mat *A,
                                         bis_mat **L_strict, bis_mat **U_strict,
                                         double *D, double *D_inv);
 
+/* Multi-colour symmetric reordering on the device (the
+ * role of SMAX's permute_mat, utilities/smax_helpers.hpp:44-80): greedy
+ * first-fit colouring in natural row order, rows grouped by colour (stable),
+ * B = P A P^T with perm[new] = old written to perm_dev (device, n int32; e.g.
+ * storage from bis_vec_alloc).  The strict triangles of B have one dependency
+ * level per colour.  BIS_ERR_UNSUPPORTED if more than 64 colours are needed.
+ * bis_vec_gather: out[i] = in[perm[i]] (permute b, x_0; out != in). */
+BIS_API bis_status bis_mat_multicolour(bis_ctx *ctx, const bis_mat *A,
+                                       bis_mat **B, int32_t *perm_dev,
+                                       int *n_colours);
+BIS_API bis_status bis_vec_gather(bis_ctx *ctx, double *out, const double *in,
+                                  const int32_t *perm_dev, int64_t n);
+
 /* ILU(0) on the device: the arithmetic of the
  * reference's serial factor_ILU0_old (utilities/LU_factors.hpp:320-539),
  * scheduled by the dependency levels of A's strict lower triangle (its
