@@ -184,6 +184,7 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_TRSV_GRID")) v.trsv_grid = atoi(e);
         if (const char *e = getenv("BIS_TRSV_ONE_XCD")) v.trsv_one_xcd = atoi(e);
         if (const char *e = getenv("BIS_ILU0_WAVE")) v.ilu0_wave = atoi(e);
+        if (const char *e = getenv("BIS_TRSV_HOST_ANALYSIS")) v.trsv_host_analysis = atoi(e);
         if (const char *e = getenv("BIS_SPMV_PACKED")) v.spmv_packed = atoi(e);
         return v;
     }();
@@ -204,6 +205,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_grid")) o.trsv_grid = value;
     else if (!strcmp(name, "trsv_one_xcd")) o.trsv_one_xcd = value;
     else if (!strcmp(name, "trsv_batch")) o.trsv_batch = value;
+    else if (!strcmp(name, "trsv_host_analysis")) o.trsv_host_analysis = value;
     else if (!strcmp(name, "ilu0_wave")) o.ilu0_wave = value;
     else if (!strcmp(name, "trsv_by_pos")) o.trsv_by_pos = value;
     else if (!strcmp(name, "spmv_packed")) o.spmv_packed = value;

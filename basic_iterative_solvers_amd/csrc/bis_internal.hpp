@@ -61,6 +61,7 @@ struct bis_options {
     int spmv_xcd_remap = -1; // 1: each XCD sweeps its own slab of row blocks (default: blockIdx order)
     int trsv_grid = -1;    // -1: automatic
     int ilu0_wave = -1;    // 0: lane-per-row ILU(0) level kernel (default: wave per row)
+    int trsv_host_analysis = -1; // 1: level analysis on the host (default: on the device)
     int trsv_batch = -1;   // dependencies polled per round trip (4, 8, 16; -1: by row length)
     int trsv_by_pos = -1;  // 1 (default): sentinel scratch in level order; 0: in row order
     int trsv_one_xcd = -1; // k > 0: sync-free sweeps run on one elected XCD with k workgroups per CU
@@ -225,6 +226,10 @@ void bis_mat_free_meta(bis_mat *A);
 void bis_trsv_plan_destroy(bis_trsv_plan *p);
 bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
                                      bis_mat **U_strict, double *D, double *D_inv, bool check_diag);
+// device-side level analysis of a strictly triangular matrix (bis_analysis.hip)
+bis_status bis_trsv_analyse_device(bis_ctx *ctx, const bis_mat *T, bool backward, int32_t *perm_dev,
+                                   std::vector<int64_t> &level_ptr, int &n_levels, int64_t &max_width,
+                                   bool &triangular);
 // dependency levels of a strict-lower matrix: host level boundaries + device row list
 bis_status bis_trsv_level_sets(bis_ctx *ctx, const bis_mat *T_lower, const std::vector<int64_t> **level_ptr,
                                const int32_t **perm_dev);

@@ -285,26 +285,42 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
     bis_trsv_plan *&slot = backward ? M->plan_bwd : M->plan_fwd;
     if (slot) { *out = slot; return BIS_OK; }
     const int64_t n = T->n_rows;
-    std::vector<int64_t> rp(n + 1);
-    std::vector<int32_t> col((size_t)std::max<int64_t>(T->nnz, 1));
-    bis_status st = bis_mat_download(ctx, T, rp.data(), col.data(), nullptr);
-    if (st != BIS_OK) return st;
-    if (!check_triangular(rp.data(), col.data(), n, backward)) {
-        ctx->err = backward ? "bis_bsptrsv: matrix is not strictly upper triangular"
-                            : "bis_sptrsv: matrix is not strictly lower triangular";
-        return BIS_ERR_INVALID;
-    }
+    bis_status st = BIS_OK;
     std::vector<int32_t> perm;
     bis_trsv_plan *p = new bis_trsv_plan;
     p->n = n;
-    build_perm(rp.data(), col.data(), n, backward, perm, p->n_levels, p->max_level_width, p->level_ptr);
     hipError_t e = hipMalloc(&p->perm, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1));
     if (e == hipSuccess) e = hipMalloc(&p->xs, sizeof(double) * (size_t)std::max<int64_t>(n, 1));
     if (e == hipSuccess) e = hipMalloc(&p->ticket, sizeof(unsigned) * 4);
-    if (e == hipSuccess && n)
-        e = hipMemcpyAsync(p->perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice,
-                           ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->err = std::string("sptrsv plan: ") + hipGetErrorString(e);
+        bis_trsv_plan_destroy(p);
+        return BIS_ERR_HIP;
+    }
+    const char *not_tri = backward ? "bis_bsptrsv: matrix is not strictly upper triangular"
+                                   : "bis_sptrsv: matrix is not strictly lower triangular";
+    if (bis_opts().trsv_host_analysis <= 0) {
+        // levels, level-sorted rows and the structure check on the device (bis_analysis.hip)
+        bool triangular = true;
+        st = bis_trsv_analyse_device(ctx, T, backward, p->perm, p->level_ptr, p->n_levels, p->max_level_width, triangular);
+        if (st == BIS_OK && !triangular) { ctx->err = not_tri; st = BIS_ERR_INVALID; }
+        if (st != BIS_OK) { bis_trsv_plan_destroy(p); return st; }
+        if (p->n_levels <= kFewLevels && n > 0) { // the contiguity test below reads the permutation
+            perm.resize(n);
+            e = hipMemcpyAsync(perm.data(), p->perm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+    } else { // host version: download the pattern and walk it serially
+        std::vector<int64_t> rp(n + 1);
+        std::vector<int32_t> col((size_t)std::max<int64_t>(T->nnz, 1));
+        st = bis_mat_download(ctx, T, rp.data(), col.data(), nullptr);
+        if (st == BIS_OK && !check_triangular(rp.data(), col.data(), n, backward)) { ctx->err = not_tri; st = BIS_ERR_INVALID; }
+        if (st != BIS_OK) { bis_trsv_plan_destroy(p); return st; }
+        build_perm(rp.data(), col.data(), n, backward, perm, p->n_levels, p->max_level_width, p->level_ptr);
+        if (n)
+            e = hipMemcpyAsync(p->perm, perm.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
     if (e != hipSuccess) {
         ctx->err = std::string("sptrsv plan: ") + hipGetErrorString(e);
         bis_trsv_plan_destroy(p);
