@@ -205,6 +205,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_grid")) o.trsv_grid = value;
     else if (!strcmp(name, "trsv_one_xcd")) o.trsv_one_xcd = value;
     else if (!strcmp(name, "trsv_batch")) o.trsv_batch = value;
+    else if (!strcmp(name, "trsv_wave")) o.trsv_wave = value;
     else if (!strcmp(name, "trsv_host_analysis")) o.trsv_host_analysis = value;
     else if (!strcmp(name, "ilu0_wave")) o.ilu0_wave = value;
     else if (!strcmp(name, "trsv_by_pos")) o.trsv_by_pos = value;

@@ -199,6 +199,77 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
     }
 }
 
+// Wave-per-row form for rows of more than 8 dependencies: the 64 lanes of a
+// wave load and poll up to 64 dependencies of ONE row together -- every pending
+// word is refreshed on every trip at O(1) instructions, no batches in sequence --
+// and the sum is then accumulated in CRS order by a scalar loop over the lanes
+// (v_readlane), i.e. the reference's fma chain exactly.  Waves take tickets (one
+// row each) in level order; lanes of a wave never wait for each other, so the
+// wait loop is an ordinary loop here.
+template <typename RP>
+__global__ __launch_bounds__(kTrsvT) void sptrsv_wave_kernel(
+    const RP *__restrict__ row_ptr, const int32_t *__restrict__ dep, const double *__restrict__ val,
+    const int32_t *__restrict__ perm, int64_t n, const double *__restrict__ D, const double *b, double *x,
+    unsigned long long *xs, unsigned *ticket, int by_pos) {
+    const int lane = threadIdx.x & 63;
+    // Static round robin over the level-sorted positions, no ticket counter (one atomic
+    // per row on one address caps the sweep at ~88 M rows/s: 11.4 ns per row measured).
+    // Progress: a wave walks its positions in ascending order and waits only for smaller
+    // positions, so by induction every position completes PROVIDED all waves of the
+    // grid are resident -- the launch keeps the grid at <= 4 workgroups per CU.
+    const int64_t n_waves = (int64_t)gridDim.x * (kTrsvT / 64);
+    const int64_t wave0 = (int64_t)blockIdx.x * (kTrsvT / 64) + (threadIdx.x >> 6);
+    for (int64_t pos = wave0; pos < n; pos += n_waves) {
+        const int r = perm[pos];
+        const int64_t s = (int64_t)row_ptr[r], e = (int64_t)row_ptr[r + 1];
+        const double rhs = b[r], d = D[r];
+        double acc = 0.0;
+        bool lost = false;
+        for (int64_t k0 = s; k0 < e; k0 += 64) {
+            const int64_t k = k0 + lane;
+            const bool active = k < e;
+            const int pc = active ? dep[k] : 0;
+            const double av = active ? val[k] : 0.0;
+            unsigned long long v = active ? __hip_atomic_load(&xs[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            unsigned spins = 0;
+            while (__any(active && v == kSentinel)) {
+                if (active && v == kSentinel) v = __hip_atomic_load(&xs[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > kSpinLimit) { lost = true; break; } // bounded: publishes NaN below
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const int cnt = (int)(e - k0 < 64 ? e - k0 : 64);
+            const unsigned vlo = (unsigned)v, vhi = (unsigned)(v >> 32);
+            const unsigned long long ab = (unsigned long long)__double_as_longlong(av);
+            const unsigned alo = (unsigned)ab, ahi = (unsigned)(ab >> 32);
+            for (int j = 0; j < cnt; ++j) { // CRS order, one fma per dependency
+                // readlane returns int: go through unsigned, or the low word sign-extends into the high one
+                const unsigned long long xv = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vhi, j) << 32) |
+                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vlo, j);
+                const unsigned long long aa = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ahi, j) << 32) |
+                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)alo, j);
+                acc = fma(__longlong_as_double((long long)aa), __longlong_as_double((long long)xv), acc);
+            }
+        }
+        const double res = (rhs - acc) / d;
+        unsigned long long out = (unsigned long long)__double_as_longlong(res);
+        if (res != res || lost) out = kCanonNaN; // never publish the sentinel pattern
+        // Lane 0 publishes -- predicated inside volatile asm, not `if (lane == 0)`: a
+        // divergent branch at the tail of the ticket loop lets the compiler send the other
+        // 63 lanes into the next trip without lane 0 (they never take a ticket and spin
+        // on ticket 0 forever, and lane 0's store waits for them at the loop exit).
+        {
+            unsigned long long *dst = &xs[by_pos ? pos : (int64_t)r];
+            unsigned long long *dx = reinterpret_cast<unsigned long long *>(&x[r]);
+            const unsigned pflag = lane == 0 ? 1u : 0u;
+            unsigned long long saved_exec;
+            asm volatile("v_cmp_ne_u32_e32 vcc, 0, %4\n\ts_and_saveexec_b64 %0, vcc\n\t"
+                         "global_store_dwordx2 %1, %3, off sc1\n\tglobal_store_dwordx2 %2, %3, off\n\t"
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(saved_exec) : "v"(dst), "v"(dx), "v"(out), "v"(pflag) : "vcc", "memory");
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void invert_perm_kernel(const int32_t *__restrict__ perm, int64_t n,
                                                           int32_t *__restrict__ inv) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -429,6 +500,27 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     }
     const int32_t *dep = (by_pos && p->pcol) ? p->pcol : T->col;
     const int pos_flag = (by_pos && p->pcol) ? 1 : 0;
+    // rows of more than 8 dependencies: one wave per row (config-5 stand-in, ~35 per row: 10.8 / 25.3 ms per
+    // forward / backward sweep with a lane per row -> 6.0 / 6.0 ms; HPCG-128, 13 per row: 2.88 / 3.05 -> 2.64 / 2.66;
+    // Anderson-256, 3 per row and 22 K rows per level: 2.4 ms with a lane per row, 8.6 ms with a wave per row)
+    const int wave_mode = bis_opts().trsv_wave >= 0 ? bis_opts().trsv_wave : (T->max_row_nnz > 8 ? 1 : 0);
+    if (wave_mode && !one_xcd) {
+        // a few levels of rows in flight, one row per wave; at most 4 workgroups per CU: every wave of the
+        // grid must be resident (static round robin, see the kernel)
+        int64_t wg = (4 * p->max_level_width + 3) / 4 + 1;
+        if (bis_opts().trsv_grid > 0) wg = bis_opts().trsv_grid;
+        wg = std::max<int64_t>(1, std::min<int64_t>(wg, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->n_cus * 4)));
+        if (T->rp64)
+            hipLaunchKernelGGL(sptrsv_wave_kernel<int64_t>, dim3((unsigned)wg), dim3(kTrsvT), 0, ctx->stream,
+                               (const int64_t *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,
+                               (unsigned long long *)p->xs, p->ticket, pos_flag);
+        else
+            hipLaunchKernelGGL(sptrsv_wave_kernel<int32_t>, dim3((unsigned)wg), dim3(kTrsvT), 0, ctx->stream,
+                               (const int32_t *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,
+                               (unsigned long long *)p->xs, p->ticket, pos_flag);
+        BIS_HIP_CHECK(ctx, hipGetLastError());
+        return BIS_OK;
+    }
 #define BIS_TRSV_LAUNCH(RP, ONE, B)                                                                    \
     hipLaunchKernelGGL((sptrsv_syncfree_kernel<RP, ONE, B>), dim3(grid), dim3(kTrsvT), 0, ctx->stream, \
                        (const RP *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,                      \

@@ -20,6 +20,7 @@ for c in cfgs:
     lib.bis_set_option(b"trsv_grid", int(c.get("grid", -1)))
     lib.bis_set_option(b"trsv_batch", int(c.get("batch", -1)))
     lib.bis_set_option(b"trsv_by_pos", int(c.get("pos", -1)))
+    lib.bis_set_option(b"trsv_wave", int(c.get("wave", -1)))
     ctx.sptrsv(Ls, x, D, b); ctx.sync()
     got = x.to_host()
     if ref is None: ref = got
