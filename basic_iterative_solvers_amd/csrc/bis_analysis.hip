@@ -40,10 +40,11 @@ __global__ __launch_bounds__(256) void level_kernel(const RP *__restrict__ row_p
         const int64_t base = (int64_t)t * 256;
         if (base >= n) return;
         const int64_t i = base + threadIdx.x;
-        if (i < n) {
-            const int64_t r = BACKWARD ? n - 1 - i : i;
-            int64_t k = (int64_t)row_ptr[r];
-            const int64_t e = (int64_t)row_ptr[r + 1];
+        const bool valid = i < n; // lanes past the end run an empty row (no divergent branch at the loop tail)
+        {
+            const int64_t r = valid ? (BACKWARD ? n - 1 - i : i) : 0;
+            int64_t k = valid ? (int64_t)row_ptr[r] : 0;
+            const int64_t e = valid ? (int64_t)row_ptr[r + 1] : 0;
             int lvl = 0;
             bool bad = false, lost = false, done = false;
             unsigned spins = 0;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void level_kernel(const RP *__restrict__ row_p
                 }
                 {
                     int *dst = &level[r];
-                    const unsigned pflag = publish ? 1u : 0u;
+                    const unsigned pflag = (publish && valid) ? 1u : 0u;
                     unsigned long long saved_exec;
                     asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %0, vcc\n\t"
                                  "global_store_dword %1, %2, off sc1\n\ts_mov_b64 exec, %0"
@@ -101,8 +102,10 @@ __global__ __launch_bounds__(256) void level_kernel(const RP *__restrict__ row_p
                 }
                 if (publish) done = true;
             }
-            if (bad) atomicExch(&status[0], 1);
-            if (lost) atomicExch(&status[1], 1);
+            // error flags behind wave-uniform conditions only: a divergent branch at the tail of
+            // the ticket loop would let some lanes run ahead into the next trip's barrier
+            if (__any(bad)) atomicOr(&status[0], bad ? 1 : 0);
+            if (__any(lost)) atomicOr(&status[1], lost ? 1 : 0);
             atomicMax(&status[2], lvl);
         }
     }

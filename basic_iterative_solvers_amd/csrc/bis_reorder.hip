@@ -48,10 +48,11 @@ __global__ __launch_bounds__(256) void greedy_colour_kernel(const RP *__restrict
         __syncthreads();
         const int64_t base = (int64_t)t * 256;
         if (base >= n) return;
-        const int64_t r = base + threadIdx.x;
-        if (r < n) {
-            int64_t k = (int64_t)row_ptr[r];
-            const int64_t e = (int64_t)row_ptr[r + 1];
+        const bool valid = base + threadIdx.x < n; // lanes past the end run an empty row (no divergent branch at the loop tail)
+        const int64_t r = valid ? base + threadIdx.x : 0;
+        {
+            int64_t k = valid ? (int64_t)row_ptr[r] : 0;
+            const int64_t e = valid ? (int64_t)row_ptr[r + 1] : 0;
             unsigned long long used = 0ull;
             bool overflow = false, done = false;
             unsigned spins = 0;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void greedy_colour_kernel(const RP *__restrict
                 }
                 {
                     int *dst = &colour[r];
-                    const unsigned pflag = publish ? 1u : 0u;
+                    const unsigned pflag = (publish && valid) ? 1u : 0u;
                     unsigned long long saved_exec;
                     asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %0, vcc\n\t"
                                  "global_store_dword %1, %2, off sc1\n\ts_mov_b64 exec, %0"
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(256) void greedy_colour_kernel(const RP *__restrict
                 }
                 if (publish) done = true;
             }
-            if (overflow) atomicExch(status, 1);
+            // wave-uniform condition: no divergent branch at the tail of the ticket loop
+            if (__any(overflow)) atomicOr(status, overflow ? 1 : 0);
         }
     }
 }

@@ -105,11 +105,15 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
         const int64_t base = (int64_t)t * kTrsvT;
         if (base >= n) return; // every wave reaches this once tickets run out
         const int64_t pos = base + threadIdx.x;
-        if (pos < n) {
-            const int r = perm[pos];
-            int64_t k = (int64_t)row_ptr[r];
-            const int64_t e = (int64_t)row_ptr[r + 1];
-            const double rhs = b[r], d = D[r];
+        // No `if (pos < n)` around the row: a divergent branch that ends at the tail of the ticket
+        // loop may be merged with the back edge, and the skipping lanes would then reach the next
+        // trip's barrier ahead of their wave.  Lanes past the end run an empty row, stores masked.
+        const bool valid = pos < n;
+        {
+            const int r = valid ? perm[pos] : 0;
+            int64_t k = valid ? (int64_t)row_ptr[r] : 0;
+            const int64_t e = valid ? (int64_t)row_ptr[r + 1] : 0;
+            const double rhs = valid ? b[r] : 0.0, d = valid ? D[r] : 1.0;
             const int64_t slot = by_pos ? pos : (int64_t)r; // where this row's result is published
             double acc = 0.0;
             unsigned spins = 0;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
                     // depend on each other wait forever (observed: ROCm 7.2, both with a plain
                     // agent-scope atomic store and with an asm store inside the if).
                     unsigned long long *dst = &xs[slot];
-                    const unsigned pflag = publish ? 1u : 0u;
+                    const unsigned pflag = (publish && valid) ? 1u : 0u;
                     unsigned long long saved_exec;
                     if (ONE_XCD)
                         asm volatile("v_cmp_ne_u32_e32 vcc, 0, %3\n\ts_and_saveexec_b64 %0, vcc\n\t"
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
                                      : "=&s"(saved_exec) : "v"(dst), "v"(out), "v"(pflag) : "vcc", "memory");
                 }
                 if (publish) {
-                    x[r] = __longlong_as_double((long long)out); // nobody polls x: may sink out of the loop
+                    if (valid) x[r] = __longlong_as_double((long long)out); // nobody polls x: may sink out of the loop
                     done = true;
                 }
             }
