@@ -18,8 +18,17 @@ def run_distributed(args, rank, world, local_rank):
     from .launcher import even_row_starts, route_send_lists, setup_rccl, torch_comm_ops
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    host_group = td.new_group(backend="gloo")  # host-side object routing
+    # BIS_BENCH_REHEARSE=1 (tests on a one-GPU box): every rank uses cuda:0, gloo process group,
+    # torch.distributed transport through the C-ABI callbacks -- everything of this function except RCCL.
+    rehearse = os.environ.get("BIS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
+        torch.cuda.set_device(0)
+        td.init_process_group("gloo")
+        host_group = None
+    else:
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        host_group = td.new_group(backend="gloo")  # host-side object routing
 
     ctx = Context(local_rank)
     n1 = args.size
@@ -32,16 +41,18 @@ def run_distributed(args, rank, world, local_rank):
     route_send_lists(d, td, group=host_group)
     transport = "rccl (native ncclSend/ncclRecv + ncclAllReduce on the library's streams)"
     try:
+        if rehearse:
+            raise BisError("rehearsal: RCCL cannot put two ranks on one GPU")
         setup_rccl(ctx, d, td, group=host_group)
         ok = 1
-XX
+    except (BisError, OSError, RuntimeError) as ex:  # e.g. RCCL not loadable: fall back to torch.distributed's communicator
         print(f"rank {rank}: native RCCL transport unavailable ({ex}); using torch.distributed", flush=True)
         ok = 0
     flag = torch.tensor([ok], device="cuda")
     td.all_reduce(flag, op=td.ReduceOp.MIN)
     if int(flag.item()) == 0:
         d.set_comm(torch_comm_ops(td, torch, world, rank))
-        transport = "torch.distributed (nccl backend) through the C-ABI communicator callbacks"
+        transport = "torch.distributed through the C-ABI communicator callbacks"
     nl = d.n_local
     b, x = ctx.alloc(nl), ctx.alloc(nl)
     ctx.init_vector(b, 1.0)

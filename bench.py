@@ -92,6 +92,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
                              "(one process per GPU)")
+    if os.environ.get("BIS_BENCH_REHEARSE") == "1":
+        local_rank = 0  # one-GPU rehearsal of the N > 1 path (tests/test_dist.py)
     torch.cuda.set_device(local_rank)
 
     from basic_iterative_solvers_amd import Context

@@ -57,3 +57,18 @@ def test_no_cpu_fallback_without_device(lib):
     from basic_iterative_solvers_amd import BisError, Context
     with pytest.raises(BisError):
         Context()
+
+
+def test_python_sources_compile():
+    """Every Python file that ships (package, bench, entry point, tools, tests) byte-compiles --
+    the multi-GPU bench path cannot be imported on a one-GPU box, so a syntax error there
+    would otherwise surface only in the driver's N > 1 run."""
+    import glob
+    import py_compile
+    files = ([os.path.join(ROOT, f) for f in ("bench.py", "__graft_entry__.py")] +
+             glob.glob(os.path.join(ROOT, "basic_iterative_solvers_amd", "*.py")) +
+             glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "oracle", "*.py")) +
+             glob.glob(os.path.join(ROOT, "tests", "*.py")))
+    assert len(files) > 15
+    for f in files:
+        py_compile.compile(f, doraise=True)

@@ -39,3 +39,27 @@ def test_partitioned_cg_gloo_cpu(world, kind, size):
 @pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 12), (3, "anderson", 7), (1, "hpcg", 8)])
 def test_partitioned_cg_hip(world, kind, size):
     launch(world, "gpu", kind, size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,precond", [(2, "none"), (3, "j")])
+def test_bench_multi_gpu_path_rehearsal(world, precond):
+    """bench.py --gpus N exactly as the driver launches it (torch.distributed.run, one process
+    per rank), on ONE GPU: BIS_BENCH_REHEARSE=1 puts every rank on cuda:0 with the gloo
+    transport, so everything of the N > 1 bench except RCCL itself runs -- partition,
+    closed-form residual check, timed loop, max-over-ranks, the JSON line."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "48", "--steps", "6", "--warmup", "2",
+           "--precond", precond]
+    env = dict(os.environ, OMP_NUM_THREADS="1", BIS_BENCH_REHEARSE="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["steps"] == 6 and j["warmup"] == 2 and j["scaling"] == "strong"
+    assert j["value"] > 0 and j["unit"] == "CG iterations/s" and j["config"]["rows"] == 48 ** 3
+    assert j["roofline"]["achieved"] > 0 and j["roofline"]["peak"] == 8000.0 * world
+    assert 0 < j["residual_last"] < j["residual_r0"] * 10
