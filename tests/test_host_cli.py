@@ -135,3 +135,20 @@ def test_cli_multicolour_reordering_vs_oracle_on_permuted_matrix(tmp_path, oracl
     check_history(r, e, solver)
     if solver != "bi":
         assert abs(r["iters"] - o["iters"]) <= 1
+
+
+@pytest.mark.parametrize("name,solver,pc,scale", [("FDM-2d-16", "cg", "sgs", True), ("matrix_band_klein", "gs", "none", True),
+                                                  ("hpcg_4x6x5", "gm", "gs", False), ("anderson8_shift9", "bi", "ilu0", True)])
+def test_cli_device_and_host_reordering_agree(tmp_path, name, solver, pc, scale):
+    """-perm mc on the device (bis_mat_multicolour, bis_vec_gather for the rescaled b) and the
+    host fallback (-perm-host) build the same permutation and the same P A P^T: identical
+    permutation files and residual tables that agree to rounding of the device reductions."""
+    kw = {"num_scale": True} if scale else {}
+    if solver == "gm":
+        kw["restart_len"] = 30
+    f1, f2 = str(tmp_path / "p_dev.txt"), str(tmp_path / "p_host.txt")
+    a = run_cli(name, solver, pc, kw, extra=["-perm", "mc", "-dump-perm", f1])
+    b = run_cli(name, solver, pc, kw, extra=["-perm", "mc", "-perm-host", "-dump-perm", f2])
+    assert np.array_equal(np.loadtxt(f1, dtype=np.int64), np.loadtxt(f2, dtype=np.int64))
+    assert a["iters"] == b["iters"] and len(a["hist"]) == len(b["hist"])
+    assert np.max(np.abs(a["hist"] - b["hist"])) <= 1e-12 * a["hist"][0]
