@@ -186,6 +186,7 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_ILU0_WAVE")) v.ilu0_wave = atoi(e);
         if (const char *e = getenv("BIS_TRSV_HOST_ANALYSIS")) v.trsv_host_analysis = atoi(e);
         if (const char *e = getenv("BIS_SPMV_PACKED")) v.spmv_packed = atoi(e);
+        if (const char *e = getenv("BIS_SPMV_PACKED32")) v.spmv_packed32 = atoi(e);
         return v;
     }();
     return o;
@@ -211,6 +212,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_by_pos")) o.trsv_by_pos = value;
     else if (!strcmp(name, "spmv_packed")) o.spmv_packed = value;
     else if (!strcmp(name, "spmv_lds_pad")) o.spmv_lds_pad = value;
+    else if (!strcmp(name, "spmv_packed32")) o.spmv_packed32 = value;
     else return BIS_ERR_INVALID;
     return BIS_OK;
 }

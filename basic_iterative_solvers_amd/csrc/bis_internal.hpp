@@ -66,6 +66,7 @@ struct bis_options {
     int trsv_batch = -1;   // dependencies polled per round trip (4, 8, 16; -1: by row length)
     int trsv_by_pos = -1;  // 1 (default): sentinel scratch in level order; 0: in row order
     int trsv_one_xcd = -1; // k > 0: sync-free sweeps run on one elected XCD with k workgroups per CU
+    int spmv_packed32 = -1; // 1: also try the 32-window packed format (opt-in)
     int spmv_lds_pad = -1; // diagnostic: extra dynamic LDS bytes per workgroup (lowers occupancy)
     int spmv_packed = -1;  // 16-bit packed column stream: 0 off, 1 select tree, 2 lane permute (-1: default = 1)
 };
@@ -105,6 +106,7 @@ struct bis_mat {
     int32_t *pk_seg[2] = {nullptr, nullptr}; // [n_blocks * 8]
     int64_t pk_base[2] = {0, 0};
     int pk_state[2] = {0, 0};
+    int pk_kind[2] = {0, 0};   // 1: 8 windows x 8192 columns, 3: 32 windows x 2048 columns
     // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
     int32_t *blkf_row = nullptr;
     int64_t *blkf_nnz = nullptr;

@@ -44,10 +44,15 @@ __device__ __forceinline__ double x_at(const char *xb, int c) {
 }
 
 constexpr int kPkSegs = 8, kPkOffBits = 13, kPkSpan = 1 << kPkOffBits;
+constexpr int kPk3Segs = 32, kPk3OffBits = 11; // second format: more, narrower windows (reordered matrices)
 
 template <int PK>
 __device__ __forceinline__ int pk_decode(unsigned code, const int (&B)[8], int lane_base, int col_max) {
     int base;
+    if (PK == 3) { // 32 windows of 2048 columns: window:5 | offset:11, lane j < 32 of every wave holds base j
+        base = __builtin_amdgcn_ds_bpermute((int)((code >> (kPk3OffBits - 2)) & 124u), lane_base);
+        return min(base + (int)(code & ((1u << kPk3OffBits) - 1)), col_max);
+    }
     if (PK == 2) {
         base = __builtin_amdgcn_ds_bpermute((int)((code >> (kPkOffBits - 2)) & 28u), lane_base);
     } else {
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
         for (int i = 0; i < 8; ++i) segb[i] = seg_base[(size_t)b * 8 + i];
     }
     if (PK == 2) lane_base = seg_base[(size_t)b * 8 + (threadIdx.x & 7)];
+    if (PK == 3) lane_base = seg_base[(size_t)b * kPk3Segs + (threadIdx.x & (kPk3Segs - 1))];
     const char *xb = reinterpret_cast<const char *>(x);
 
     // phase 1: stream val/col, gather x, park products.  Branch-free up to the
@@ -423,24 +429,26 @@ __global__ __launch_bounds__(T) void spmv_window_kernel(
 // uncovered column (so the bases come out ascending); more than 8 windows ->
 // the matrix keeps the 32-bit column stream.
 // ---------------------------------------------------------------------------
+template <int SEGS, int OFFBITS>
 __global__ __launch_bounds__(256) void pk_build_kernel(const int32_t *__restrict__ col,
                                                        const int64_t *__restrict__ blk_nnz, int n_blocks,
                                                        int64_t pk_base, uint16_t *__restrict__ pk,
                                                        int32_t *__restrict__ seg_base, int *__restrict__ status) {
-    __shared__ int base[kPkSegs];
+    constexpr int SPAN = 1 << OFFBITS;
+    __shared__ int base[SEGS];
     __shared__ int cur;
     const int b = blockIdx.x;
     if (b >= n_blocks) return;
     const int64_t s = blk_nnz[b], e = blk_nnz[b + 1];
     int n_seg = 0;
-    for (int sg = 0; sg <= kPkSegs; ++sg) {
+    for (int sg = 0; sg <= SEGS; ++sg) {
         if (threadIdx.x == 0) cur = INT32_MAX;
         __syncthreads();
         int m = INT32_MAX;
         for (int64_t k = s + threadIdx.x; k < e; k += 256) {
             const int c = col[k];
             bool covered = false;
-            for (int i = 0; i < sg; ++i) covered |= (c >= base[i] && c - base[i] < kPkSpan);
+            for (int i = 0; i < sg; ++i) covered |= (c >= base[i] && c - base[i] < SPAN);
             if (!covered) m = min(m, c);
         }
         if (m != INT32_MAX) atomicMin(&cur, m);
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(256) void pk_build_kernel(const int32_t *__restrict
         const int found = cur;
         __syncthreads();
         if (found == INT32_MAX) break;
-        if (sg == kPkSegs) { // a ninth window would be needed
+        if (sg == SEGS) { // one window too many
             if (threadIdx.x == 0) atomicExch(&status[0], 1);
             return;
         }
@@ -456,12 +464,12 @@ __global__ __launch_bounds__(256) void pk_build_kernel(const int32_t *__restrict
         n_seg = sg + 1;
         __syncthreads();
     }
-    if (threadIdx.x < kPkSegs) seg_base[(size_t)b * kPkSegs + threadIdx.x] = (int)threadIdx.x < n_seg ? base[threadIdx.x] : 0;
+    if (threadIdx.x < SEGS) seg_base[(size_t)b * SEGS + threadIdx.x] = (int)threadIdx.x < n_seg ? base[threadIdx.x] : 0;
     for (int64_t k = s + threadIdx.x; k < e; k += 256) {
         const int c = col[k];
         int sg = 0;
         for (int i = 1; i < n_seg; ++i) sg += base[i] <= c; // ascending bases: last one not above c
-        pk[k - pk_base] = (uint16_t)((sg << kPkOffBits) | (c - base[sg]));
+        pk[k - pk_base] = (uint16_t)((sg << OFFBITS) | (c - base[sg]));
     }
 }
 
@@ -489,6 +497,7 @@ void launch_variant(const SpmvArgs &a) {
     if (a.wide) BIS_LVM(-1);
     else if (a.pk_mode == 1) BIS_LVM(1);
     else if (a.pk_mode == 2) BIS_LVM(2);
+    else if (a.pk_mode == 3) BIS_LVM(3);
     else BIS_LVM(0);
 #undef BIS_LVM
 #undef BIS_LV
@@ -534,7 +543,10 @@ int grid_for_map(int nb, int remap_arg) {
 int fused_threads(int) { return 256; }
 
 // default: the branch-free 2-stage form with the packed stream, the staged 4-deep form with 32-bit columns
-int spmv_variant(const SpmvArgs &a) { return bis_opts().spmv_variant >= 0 ? bis_opts().spmv_variant : (a.pk_mode ? 20 : 41); }
+int spmv_variant(const SpmvArgs &a) {
+    const int v = bis_opts().spmv_variant >= 0 ? bis_opts().spmv_variant : (a.pk_mode ? 20 : 41);
+    return (a.pk_mode >= 2 && v % 10 != 0) ? 20 : v; // the lane-permute decodes need the whole wave: branch-free form only
+}
 
 } // namespace
 
@@ -604,21 +616,30 @@ bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t) {
     A->pk_base[t] = ends[0] & ~(int64_t)3;
     const size_t n_pk = (size_t)(ends[1] - A->pk_base[t]) + 16;
     BIS_HIP_CHECK(ctx, hipMalloc(&A->pk[t], sizeof(uint16_t) * n_pk));
-    BIS_HIP_CHECK(ctx, hipMalloc(&A->pk_seg[t], sizeof(int32_t) * (size_t)nb * kPkSegs));
-    BIS_HIP_CHECK(ctx, hipMemsetAsync(A->pk[t], 0, sizeof(uint16_t) * n_pk, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->pk_seg[t], sizeof(int32_t) * (size_t)nb * kPk3Segs));
     int *status = (int *)ctx->counters + 44;
-    BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(pk_build_kernel, dim3(nb), dim3(256), 0, ctx->stream, A->col, tab, nb, A->pk_base[t],
-                       A->pk[t], A->pk_seg[t], status);
-    BIS_HIP_CHECK(ctx, hipGetLastError());
-    int h = 0;
-    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h) {
+    // format 1: 8 windows of 8192 columns (select-tree decode); format 3: 32 windows of 2048 columns
+    // (lane-permute decode) for matrices whose rows reach into many short column runs, e.g. after
+    // a multi-colour reordering
+    for (int kind = 1; kind <= 3; kind += 2) {
+        if (kind == 3 && bis_opts().spmv_packed32 <= 0) break; // opt-in: measured no gain
+        BIS_HIP_CHECK(ctx, hipMemsetAsync(A->pk[t], 0, sizeof(uint16_t) * n_pk, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
+        if (kind == 1)
+            hipLaunchKernelGGL((pk_build_kernel<kPkSegs, kPkOffBits>), dim3(nb), dim3(256), 0, ctx->stream, A->col, tab,
+                               nb, A->pk_base[t], A->pk[t], A->pk_seg[t], status);
+        else
+            hipLaunchKernelGGL((pk_build_kernel<kPk3Segs, kPk3OffBits>), dim3(nb), dim3(256), 0, ctx->stream, A->col, tab,
+                               nb, A->pk_base[t], A->pk[t], A->pk_seg[t], status);
+        BIS_HIP_CHECK(ctx, hipGetLastError());
+        int h = 0;
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!h) { A->pk_state[t] = 1; A->pk_kind[t] = kind; break; }
+    }
+    if (A->pk_state[t] != 1) {
         hipFree(A->pk[t]); hipFree(A->pk_seg[t]);
         A->pk[t] = nullptr; A->pk_seg[t] = nullptr;
-    } else {
-        A->pk_state[t] = 1;
     }
     return BIS_OK;
 }
@@ -636,7 +657,7 @@ static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArg
     if (A->pk_state[t] == 1) {
         a->pk = A->pk[t]; a->pk_base = A->pk_base[t]; a->seg_base = A->pk_seg[t];
         a->col_max = (int)std::max<int64_t>(A->n_cols - 1, 0);
-        a->pk_mode = spmv_packed_mode() == 2 ? 2 : 1;
+        a->pk_mode = A->pk_kind[t] == 3 ? 3 : (spmv_packed_mode() == 2 ? 2 : 1);
     }
     return BIS_OK;
 }
