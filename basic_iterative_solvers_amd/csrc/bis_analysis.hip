@@ -128,6 +128,117 @@ __global__ __launch_bounds__(256) void level_bounds_kernel(const int *__restrict
 
 } // namespace
 
+// ---------------------------------------------------------------------------
+// Contiguous independent row blocks (the schedule of a colour-sorted matrix).
+// Forward: block [b_k, b_{k+1}) may be swept by one streaming launch iff every
+// dependency of its rows lies before b_k, i.e. b_{k+1} = first r >= b_k whose
+// largest column is >= b_k.  Backward: mirrored from the end.  This needs neither
+// exact dependency levels nor a row list; a matrix that does not decompose into
+// at most max_blocks such blocks (any natural ordering) is reported as such.
+// ---------------------------------------------------------------------------
+namespace {
+
+template <typename RP, bool BACKWARD>
+__global__ __launch_bounds__(256) void row_extreme_col_kernel(const RP *__restrict__ row_ptr,
+                                                              const int32_t *__restrict__ col, int64_t n,
+                                                              int32_t *__restrict__ m, int32_t *__restrict__ iota,
+                                                              int *__restrict__ bad) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    int lo = INT32_MAX, hi = -1;
+    for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) { lo = min(lo, col[k]); hi = max(hi, col[k]); }
+    // strictly triangular, columns in range
+    if (hi >= 0 && (BACKWARD ? (lo <= r || hi >= n) : (hi >= r || lo < 0))) atomicOr(bad, 1);
+    m[r] = BACKWARD ? lo : hi;
+    if (iota) iota[r] = (int32_t)r;
+}
+
+// forward: out = min { r in [start, n) : m[r] >= start }  (n if none)
+// backward: out = max { r in [0, end) : m[r] < end }       (-1 if none)
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void block_boundary_kernel(const int32_t *__restrict__ m, int64_t n, int64_t edge,
+                                                             long long *out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    long long best = BACKWARD ? -1 : (long long)n;
+    if (BACKWARD) {
+        for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < edge; r += stride)
+            if (m[r] < edge) best = r > best ? r : best;
+    } else {
+        for (int64_t r = edge + (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride)
+            if (m[r] >= edge) { best = r; break; } // ascending per lane: the first hit is this lane's minimum
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_down(best, off, 64);
+        best = BACKWARD ? (o > best ? o : best) : (o < best ? o : best);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (BACKWARD) atomicMax(out, best); else atomicMin(out, best);
+    }
+}
+
+} // namespace
+
+// bounds: block edges in processing order (forward: b_0=0 < b_1 < ... = n; backward: n = e_0 > e_1 > ... = 0);
+// empty if the matrix needs more than max_blocks blocks.  perm_dev (optional): filled with the identity --
+// the "level-sorted" row list of a matrix whose blocks are its levels.
+bis_status bis_trsv_blocks_device(bis_ctx *ctx, const bis_mat *T, bool backward, int max_blocks,
+                                  std::vector<int64_t> &bounds, int32_t *perm_dev, bool &triangular) {
+    bounds.clear();
+    triangular = true;
+    const int64_t n = T->n_rows;
+    if (n == 0) return BIS_OK;
+    int32_t *m = nullptr;
+    long long *out = nullptr;
+    auto cleanup = [&](bis_status rc) { hipFree(m); hipFree(out); return rc; };
+#define BIS_BL_CHECK(call)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return cleanup(BIS_ERR_HIP); } \
+    } while (0)
+    BIS_BL_CHECK(hipMalloc(&m, sizeof(int32_t) * (size_t)n));
+    BIS_BL_CHECK(hipMalloc(&out, sizeof(long long) * 2));
+    int *bad = reinterpret_cast<int *>(out + 1);
+    BIS_BL_CHECK(hipMemsetAsync(out, 0, sizeof(long long) * 2, ctx->stream));
+    const unsigned n_blk = (unsigned)((n + 255) / 256);
+    if (T->rp64) {
+        if (backward) hipLaunchKernelGGL((row_extreme_col_kernel<int64_t, true>), dim3(n_blk), dim3(256), 0, ctx->stream, (const int64_t *)T->row_ptr, T->col, n, m, perm_dev, bad);
+        else hipLaunchKernelGGL((row_extreme_col_kernel<int64_t, false>), dim3(n_blk), dim3(256), 0, ctx->stream, (const int64_t *)T->row_ptr, T->col, n, m, perm_dev, bad);
+    } else {
+        if (backward) hipLaunchKernelGGL((row_extreme_col_kernel<int32_t, true>), dim3(n_blk), dim3(256), 0, ctx->stream, (const int32_t *)T->row_ptr, T->col, n, m, perm_dev, bad);
+        else hipLaunchKernelGGL((row_extreme_col_kernel<int32_t, false>), dim3(n_blk), dim3(256), 0, ctx->stream, (const int32_t *)T->row_ptr, T->col, n, m, perm_dev, bad);
+    }
+    {
+        int hb = 0;
+        BIS_BL_CHECK(hipMemcpyAsync(&hb, bad, sizeof hb, hipMemcpyDeviceToHost, ctx->stream));
+        BIS_BL_CHECK(hipStreamSynchronize(ctx->stream));
+        if (hb) { triangular = false; return cleanup(BIS_OK); }
+    }
+    std::vector<int64_t> b;
+    int64_t edge = backward ? n : 0;
+    b.push_back(edge);
+    const unsigned grid = std::min<unsigned>(n_blk, 1024);
+    while (true) {
+        const long long init = backward ? -1 : (long long)n;
+        BIS_BL_CHECK(hipMemcpyAsync(out, &init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+        if (backward) hipLaunchKernelGGL(block_boundary_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, m, n, edge, out);
+        else hipLaunchKernelGGL(block_boundary_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, m, n, edge, out);
+        long long h = 0;
+        BIS_BL_CHECK(hipMemcpyAsync(&h, out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        BIS_BL_CHECK(hipStreamSynchronize(ctx->stream));
+        const int64_t next = backward ? (int64_t)h + 1 : (int64_t)h; // backward: the block starts right after the highest violating row
+        b.push_back(next);
+        edge = next;
+        if (backward ? next <= 0 : next >= n) break;
+        // not a colour-sorted matrix: too many blocks (no shortcut on block sizes -- the last colours of a
+        // greedy colouring hold a handful of rows; a natural ordering costs max_blocks small reductions once)
+        if ((int)b.size() - 1 >= max_blocks) return cleanup(BIS_OK);
+    }
+#undef BIS_BL_CHECK
+    bounds = b;
+    return cleanup(BIS_OK);
+}
+
 // perm_dev: n int32 (device).  triangular = false: an entry on the wrong side of the
 // diagonal (or out of range) was found; the other outputs are then meaningless.
 bis_status bis_trsv_analyse_device(bis_ctx *ctx, const bis_mat *T, bool backward, int32_t *perm_dev,

@@ -233,6 +233,9 @@ bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L
 bis_status bis_trsv_analyse_device(bis_ctx *ctx, const bis_mat *T, bool backward, int32_t *perm_dev,
                                    std::vector<int64_t> &level_ptr, int &n_levels, int64_t &max_width,
                                    bool &triangular);
+// contiguous independent row blocks of a strictly triangular matrix, in processing order (bis_analysis.hip)
+bis_status bis_trsv_blocks_device(bis_ctx *ctx, const bis_mat *T, bool backward, int max_blocks,
+                                  std::vector<int64_t> &bounds, int32_t *perm_dev, bool &triangular);
 // dependency levels of a strict-lower matrix: host level boundaries + device row list
 bis_status bis_trsv_level_sets(bis_ctx *ctx, const bis_mat *T_lower, const std::vector<int64_t> **level_ptr,
                                const int32_t **perm_dev);

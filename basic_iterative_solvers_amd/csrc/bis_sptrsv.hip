@@ -374,6 +374,36 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
     }
     const char *not_tri = backward ? "bis_bsptrsv: matrix is not strictly upper triangular"
                                    : "bis_sptrsv: matrix is not strictly lower triangular";
+    bool blocks_done = false;
+    if (bis_opts().trsv_host_analysis <= 0 && n > 0 && (int64_t)T->chunk_nnz + T->max_row_nnz + 8 <= 8192) {
+        // a colour-sorted matrix decomposes into a few contiguous blocks of mutually independent rows:
+        // sweep each with the streaming SpMV kernel + triangular epilogue (no levels, no row list needed)
+        std::vector<int64_t> bounds;
+        bool triangular = true;
+        st = bis_trsv_blocks_device(ctx, T, backward, kFewLevels, bounds, backward ? nullptr : p->perm, triangular);
+        if (st == BIS_OK && !triangular) { ctx->err = not_tri; st = BIS_ERR_INVALID; }
+        if (st != BIS_OK) { bis_trsv_plan_destroy(p); return st; }
+        if (!bounds.empty()) {
+            const int nb = (int)bounds.size() - 1;
+            for (int l = 0; l < nb && st == BIS_OK; ++l) {
+                const int64_t r0 = backward ? bounds[l + 1] : bounds[l], r1 = backward ? bounds[l] : bounds[l + 1];
+                bis_mat *v = nullptr;
+                st = bis_mat_row_view(ctx, T, r0, r1, &v);
+                if (st == BIS_OK) { p->level_views.push_back(v); p->level_row0.push_back(r0); }
+            }
+            if (st != BIS_OK) { bis_trsv_plan_destroy(p); return st; }
+            p->n_levels = nb;
+            p->max_level_width = 0;
+            for (int l = 0; l < nb; ++l) p->max_level_width = std::max<int64_t>(p->max_level_width, std::llabs(bounds[l + 1] - bounds[l]));
+            if (!backward) p->level_ptr = bounds; // forward: the blocks are levels of the identity row list (ILU(0) uses them)
+            blocks_done = true;
+        }
+    }
+    if (blocks_done) {
+        slot = p;
+        *out = p;
+        return BIS_OK;
+    }
     if (bis_opts().trsv_host_analysis <= 0) {
         // levels, level-sorted rows and the structure check on the device (bis_analysis.hip)
         bool triangular = true;
