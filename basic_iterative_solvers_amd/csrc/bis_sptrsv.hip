@@ -2,28 +2,37 @@
 // serial there) and the preconditioner dispatcher built on them
 // (kernels.hpp:312-414).
 //
-// Level-scheduled, synchronisation-free solve in ONE launch:
-//   analysis (once per matrix, host): level[r] = 1 + max level of the rows r
-//     depends on; rows are stably sorted by level into perm[] so that every
-//     dependency of the row at position i sits at a position < i.
-//   solve: a persistent grid takes 256-position tickets in order from a
-//     device counter; the lane that owns a row walks that row's non-zeros in
-//     CRS storage order -- the reference's natural-order arithmetic,
-//     acc = fma(val, x[col], acc), x[r] = (b[r]-acc)/D[r], is preserved
-//     exactly -- and waits for each x[col] it needs.  Readiness travels with
-//     the data: results are published into a scratch vector pre-filled with a
-//     NaN sentinel, by ONE 8-byte agent-scope (sc1, write-through) store per
-//     row, and consumers poll exactly that word with agent-scope relaxed loads
-//     (cdna_hip_programming.md Guideline 16, form R2 "the data IS the flag").
-//     Ticket order guarantees progress: every position a waiting lane depends
-//     on belongs to a workgroup that already holds a ticket, i.e. is resident.
-//     The store sits INSIDE the wait loop so lanes of one wave that depend on
-//     each other (a level boundary inside a wave) cannot deadlock.
+// Three execution modes, chosen from the structure of the triangle (get_plan):
+//
+//  (1) colour-sorted matrices (`-perm mc`): at most 64 contiguous blocks of mutually
+//      independent rows (bis_analysis.hip finds them on the device) -- one streaming
+//      SpMV launch with the triangular epilogue per block (bis_spmv.hip MODE 2).
+//  (2) everything else (natural orderings: hundreds to thousands of dependency
+//      levels): level-scheduled, synchronisation-free solve in ONE launch.
+//      analysis (once per matrix, on the device): level[r] = 1 + max level of the
+//        rows r depends on; rows stably sorted by level into perm[] so that every
+//        dependency of the row at position i sits at a position < i.
+//      solve: the rows are walked in level order by a persistent grid; the lane
+//        (rows of up to 8 dependencies, 256-position tickets from a device counter)
+//        or the wave (longer rows, positions dealt round-robin) that owns a row
+//        accumulates acc = fma(val, x[col], acc) in CRS storage order -- the
+//        reference's natural-order arithmetic exactly -- then x[r] = (b[r]-acc)/D[r],
+//        and waits for each x[col] it needs.  Readiness travels with the data:
+//        results are published into a scratch vector pre-filled with a NaN sentinel,
+//        kept in LEVEL order, by ONE 8-byte sc1 store per row, and consumers poll
+//        exactly that word with agent-scope relaxed loads (cdna_hip_programming.md
+//        Guideline 16, form R2 "the data IS the flag").  Every dependency belongs to
+//        an earlier position, whose owner is resident: progress is guaranteed; every
+//        spin is bounded (a lost hand-off would publish NaN instead of hanging).
+//        The publishing store is predicated inside volatile asm on the straight-line
+//        path of the wait loop -- see the hazard notes at the kernels.
+//  (3) at most 64 levels that are not contiguous: one plain launch per level.
+//
 //   The user-visible x is written with a plain store (nobody polls it), so x
 //   may alias b (gmres.hpp:173, gauss_seidel.hpp:37).
 //
 // HBM traffic ~ 12*nnz_T + 28*N algorithmic (+ 24*N for the sentinel scratch);
-// the solve is latency-bound on stencils (one cross-CU hand-off per level).
+// mode (2) is latency-bound on stencils: one cross-CU hand-off (~3 us) per level.
 #include "bis_internal.hpp"
 
 #include <algorithm>
