@@ -21,9 +21,17 @@
 //     cost more than the x re-fetches they save, which the 256 MiB Infinity
 //     Cache absorbs.  Option "spmv_xcd_remap": 0 none, 1 slabs, G>1 groups.
 //
+//   * packed column stream (default): per row block <= 8 column windows, per
+//     non-zero a 16-bit code (window:3 | offset:13) -- 10 instead of 12 streamed
+//     bytes per non-zero; the CRS arrays stay authoritative.  Falls back to the
+//     32-bit columns when a block needs more windows.
+//
 // Rows longer than the LDS budget fall back to a wave-per-row kernel.
 // An optional fused epilogue accumulates sum_r y[r]*w[r] (the (Ap,p) of
-// cg.hpp:23) into per-block partials so CG needs no separate dot pass.
+// cg.hpp:23) into per-wave partials so CG needs no separate dot pass; a third
+// epilogue turns the kernel into one triangular-sweep step on a row range.
+// Measurements, the PMC analysis of what bounds the kernel (L1->L2 request rate,
+// 93 % of the streaming rate in fabric bytes) and the tuning record: DESIGN.md 4.
 #include "bis_internal.hpp"
 
 #include <cstdlib>
