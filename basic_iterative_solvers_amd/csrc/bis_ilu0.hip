@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void sort_rows_wave_kernel(const RP *__restric
                                                              int64_t *__restrict__ dpos,
                                                              int64_t *__restrict__ ustart) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return; // whole wave
+    // grid-stride over the rows: a grid of n/4 workgroups exceeds HIP's 2^32 threads per launch
+    // for n > 67 M rows (HPCG-512)
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
     const int64_t s = rp[i], e = rp[i + 1];
     int less_tot = 0, leq_tot = 0, has_diag = 0;
     for (int64_t a0 = s; a0 < e; a0 += 64) {
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void sort_rows_wave_kernel(const RP *__restric
     if (lane == 0) {
         dpos[i] = has_diag ? s + less_tot : -1; // first entry equal to i in the sorted row
         ustart[i] = s + leq_tot;
+    }
     }
 }
 
@@ -227,7 +229,7 @@ bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot
     const RP *rp = (const RP *)W->row_ptr;
     if (n > 0) {
         if (bis_opts().ilu0_wave != 0)
-            hipLaunchKernelGGL(sort_rows_wave_kernel<RP>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(sort_rows_wave_kernel<RP>, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 1 << 22)), dim3(256), 0, ctx->stream,
                                (const RP *)A->row_ptr, A->col, A->val, n, W->col, W->val, dpos, ustart);
         else
             hipLaunchKernelGGL(sort_rows_kernel<RP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,

@@ -546,7 +546,11 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     // rows of more than 8 dependencies: one wave per row (config-5 stand-in, ~35 per row: 10.8 / 25.3 ms per
     // forward / backward sweep with a lane per row -> 6.0 / 6.0 ms; HPCG-128, 13 per row: 2.88 / 3.05 -> 2.64 / 2.66;
     // Anderson-256, 3 per row and 22 K rows per level: 2.4 ms with a lane per row, 8.6 ms with a wave per row)
-    const int wave_mode = bis_opts().trsv_wave >= 0 ? bis_opts().trsv_wave : (T->max_row_nnz > 8 ? 1 : 0);
+    // ... unless the levels are much wider than the resident waves (HPCG-512: 37 K rows per level against 4096
+    // waves: 98 ms per sweep with a wave per row) and the rows still fit two lane batches
+    const int64_t avg_width = p->n_levels > 0 ? n / p->n_levels : n;
+    const int wave_auto = T->max_row_nnz > 16 || (T->max_row_nnz > 8 && avg_width <= (int64_t)ctx->n_cus * 16);
+    const int wave_mode = bis_opts().trsv_wave >= 0 ? bis_opts().trsv_wave : (wave_auto ? 1 : 0);
     if (wave_mode && !one_xcd) {
         // a few levels of rows in flight, one row per wave; at most 4 workgroups per CU: every wave of the
         // grid must be resident (static round robin, see the kernel)

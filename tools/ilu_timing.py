@@ -11,9 +11,11 @@ def T(label, f):
     print(f"{label}: {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True); return r
 A = T("generate", lambda: ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_fem(n1) if kind == "fem" else ctx.gen_anderson(n1, shift=9.0))
 print("rows", A.n_rows, "nnz", A.nnz)
-T("split_strict", lambda: ctx.split_strict(A))
+sp = T("split_strict", lambda: ctx.split_strict(A))
+for o in sp: o.free()
 Ls, L_D, Us, U_D = T("ilu0 (1st)", lambda: ctx.ilu0(A))
-T("ilu0 (2nd)", lambda: ctx.ilu0(A))
+if A.nnz < 2**31:
+    for o in T("ilu0 (2nd)", lambda: ctx.ilu0(A)): o.free()
 N = A.n_rows
 b, x = ctx.alloc(N), ctx.alloc(N)
 ctx.init_vector(b, 1.0)
