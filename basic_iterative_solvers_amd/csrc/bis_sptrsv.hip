@@ -244,23 +244,30 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_wave_kernel(
             const int pc = active ? dep[k] : 0;
             const double av = active ? val[k] : 0.0;
             unsigned long long v = active ? __hip_atomic_load(&xs[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            unsigned spins = 0;
-            while (__any(active && v == kSentinel)) {
-                if (active && v == kSentinel) v = __hip_atomic_load(&xs[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (++spins > kSpinLimit) { lost = true; break; } // bounded: publishes NaN below
-                __builtin_amdgcn_s_sleep(1);
-            }
+            // fold the ready prefix into the sum while the later words are still awaited (CRS order kept:
+            // entries are consumed strictly left to right), so that only the tail remains after the last arrival
             const int cnt = (int)(e - k0 < 64 ? e - k0 : 64);
-            const unsigned vlo = (unsigned)v, vhi = (unsigned)(v >> 32);
             const unsigned long long ab = (unsigned long long)__double_as_longlong(av);
             const unsigned alo = (unsigned)ab, ahi = (unsigned)(ab >> 32);
-            for (int j = 0; j < cnt; ++j) { // CRS order, one fma per dependency
-                // readlane returns int: go through unsigned, or the low word sign-extends into the high one
-                const unsigned long long xv = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vhi, j) << 32) |
-                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vlo, j);
-                const unsigned long long aa = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ahi, j) << 32) |
-                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)alo, j);
-                acc = fma(__longlong_as_double((long long)aa), __longlong_as_double((long long)xv), acc);
+            unsigned spins = 0;
+            int folded = 0;
+            for (;;) {
+                const unsigned long long pend = __ballot(active && v == kSentinel);
+                const int upto = pend ? (int)__builtin_ctzll(pend) : cnt;
+                const unsigned vlo = (unsigned)v, vhi = (unsigned)(v >> 32);
+                for (int j = folded; j < upto; ++j) { // one fma per dependency, the reference's chain
+                    // readlane returns int: go through unsigned, or the low word sign-extends into the high one
+                    const unsigned long long xv = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vhi, j) << 32) |
+                                                  (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vlo, j);
+                    const unsigned long long aa = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ahi, j) << 32) |
+                                                  (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)alo, j);
+                    acc = fma(__longlong_as_double((long long)aa), __longlong_as_double((long long)xv), acc);
+                }
+                folded = upto;
+                if (!pend) break;
+                if (++spins > kSpinLimit) { lost = true; break; } // bounded: publishes NaN below
+                if (active && v == kSentinel) v = __hip_atomic_load(&xs[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_sleep(1);
             }
         }
         const double res = (rhs - acc) / d;
