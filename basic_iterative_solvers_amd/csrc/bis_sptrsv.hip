@@ -247,27 +247,38 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_wave_kernel(
             // fold the ready prefix into the sum while the later words are still awaited (CRS order kept:
             // entries are consumed strictly left to right), so that only the tail remains after the last arrival
             const int cnt = (int)(e - k0 < 64 ? e - k0 : 64);
-            const unsigned long long ab = (unsigned long long)__double_as_longlong(av);
-            const unsigned alo = (unsigned)ab, ahi = (unsigned)(ab >> 32);
             unsigned spins = 0;
             int folded = 0;
+            // The chain acc_j = fma(a_j, x_j, acc_{j-1}) runs ACROSS the lanes: in step j every lane
+            // takes its left neighbour's accumulator (DPP wave_shr:1, lane 0 takes the carry of the
+            // previous chunk) and applies its own fma; lane j's value is final after step j and
+            // recomputing it later reproduces it.  ~20 cycles per step against ~80 for a scalar loop
+            // over v_readlane.
+            double lacc = 0.0;
             for (;;) {
                 const unsigned long long pend = __ballot(active && v == kSentinel);
                 const int upto = pend ? (int)__builtin_ctzll(pend) : cnt;
-                const unsigned vlo = (unsigned)v, vhi = (unsigned)(v >> 32);
-                for (int j = folded; j < upto; ++j) { // one fma per dependency, the reference's chain
-                    // readlane returns int: go through unsigned, or the low word sign-extends into the high one
-                    const unsigned long long xv = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vhi, j) << 32) |
-                                                  (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vlo, j);
-                    const unsigned long long aa = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ahi, j) << 32) |
-                                                  (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)alo, j);
-                    acc = fma(__longlong_as_double((long long)aa), __longlong_as_double((long long)xv), acc);
+                const double xv = __longlong_as_double((long long)v);
+                for (int j = folded; j < upto; ++j) {
+                    const unsigned long long cur = (unsigned long long)__double_as_longlong(lacc);
+                    const unsigned long long seed = (unsigned long long)__double_as_longlong(acc); // carry into lane 0
+                    const unsigned tlo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)seed, (int)(unsigned)cur, 0x138, 0xf, 0xf, false);
+                    const unsigned thi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(seed >> 32), (int)(unsigned)(cur >> 32), 0x138, 0xf, 0xf, false);
+                    const double left = __longlong_as_double((long long)(((unsigned long long)thi << 32) | tlo));
+                    lacc = fma(av, xv, left);
                 }
                 folded = upto;
                 if (!pend) break;
                 if (++spins > kSpinLimit) { lost = true; break; } // bounded: publishes NaN below
                 if (active && v == kSentinel) v = __hip_atomic_load(&xs[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_s_sleep(1);
+            }
+            // the chunk's result sits in its last lane
+            {
+                const unsigned long long lb = (unsigned long long)__double_as_longlong(lacc);
+                const unsigned long long fin = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(lb >> 32), cnt - 1) << 32) |
+                                               (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)lb, cnt - 1);
+                acc = __longlong_as_double((long long)fin);
             }
         }
         const double res = (rhs - acc) / d;
