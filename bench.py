@@ -61,7 +61,7 @@ def cpu_baseline(size, precond, iters):
     D = np.full(A.n_rows, 26.0) if precond == "j" else None
     _, s1 = orc.cg_run(A, 1, D)
     if iters <= 0:  # size the sample for ~15 s of CPU work
-        iters = int(max(3, min(200, 15.0 / max(s1, 1e-3))))
+        iters = int(max(3, min(400, 15.0 / max(s1, 1e-3))))
     if pyoracle.Ref.available() and A.nnz < 2 ** 31 - 1 and os.environ.get("BIS_CPU_KIND") != "port":
         ref = pyoracle.Ref()
         r = ref.solve(A, "cg", "j" if precond == "j" else "none", max_iters=iters, tol=1e-300)
