@@ -140,6 +140,12 @@ class Context:
         store.free()
         return Mat(self, h), perm, nc.value
 
+    def tune_placement(self, A, max_trials=6):
+        """Keep the fastest of up to max_trials re-allocations of A's streamed arrays; returns (first_ms, best_ms)."""
+        f, b = C.c_double(), C.c_double()
+        self.check(self.lib.bis_mat_tune_placement(self.h, A.h, C.c_int(max_trials), C.byref(f), C.byref(b)))
+        return f.value, b.value
+
     def split_strict(self, A):
         n = A.n_rows
         D, Dinv = self.alloc(n), self.alloc(n)

@@ -187,6 +187,7 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_TRSV_HOST_ANALYSIS")) v.trsv_host_analysis = atoi(e);
         if (const char *e = getenv("BIS_SPMV_PACKED")) v.spmv_packed = atoi(e);
         if (const char *e = getenv("BIS_SPMV_PACKED32")) v.spmv_packed32 = atoi(e);
+        if (const char *e = getenv("BIS_TUNE_PLACEMENT")) v.tune_placement = atoi(e);
         return v;
     }();
     return o;
@@ -213,6 +214,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "spmv_packed")) o.spmv_packed = value;
     else if (!strcmp(name, "spmv_lds_pad")) o.spmv_lds_pad = value;
     else if (!strcmp(name, "spmv_packed32")) o.spmv_packed32 = value;
+    else if (!strcmp(name, "tune_placement")) o.tune_placement = value;
     else return BIS_ERR_INVALID;
     return BIS_OK;
 }

@@ -238,6 +238,10 @@ bis_status bis_dist_create(bis_ctx *ctx, bis_mat *A, int rank, int n_ranks, cons
     A->n_cols = d->n_local + d->n_halo;
     st = bis_mat_finalize(ctx, A); // the column indices changed: rebuild the packed stream / window structures
     if (st != BIS_OK) { hipEventDestroy(d->ev_packed); hipEventDestroy(d->ev_halo); hipStreamDestroy(d->comm_stream); delete d; return st; }
+    if (bis_opts().tune_placement > 0) { // optional setup step, before the views share A's arrays
+        st = bis_mat_tune_placement(ctx, A, bis_opts().tune_placement, nullptr, nullptr);
+        if (st != BIS_OK) { hipEventDestroy(d->ev_packed); hipEventDestroy(d->ev_halo); hipStreamDestroy(d->comm_stream); delete d; return st; }
+    }
     d->A = A;
     d->mid_a = interior[0];
     d->mid_b = interior[1];

@@ -528,6 +528,85 @@ BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A) {
     return bis_mat_finalize(ctx, A);
 }
 
+// Placement tuning: see include/bis_hip.h.
+BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_trials, double *first_ms,
+                                          double *best_ms) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A && !A->view, "bis_mat_tune_placement: owning matrix required");
+    if (first_ms) *first_ms = 0.0;
+    if (best_ms) *best_ms = 0.0;
+    if (A->nnz == 0 || A->n_rows == 0 || max_trials <= 0) return BIS_OK;
+    double *x = nullptr, *y = nullptr;
+    bis_status st = bis_vec_alloc(ctx, A->n_cols, &x);
+    if (st == BIS_OK) st = bis_vec_alloc(ctx, A->n_rows, &y);
+    if (st == BIS_OK) st = bis_init_vector(ctx, x, 1.0, A->n_cols);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (st == BIS_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) st = BIS_ERR_HIP;
+    auto measure = [&](double &ms) -> bis_status {
+        for (int i = 0; i < 2; ++i) { bis_status s2 = bis_spmv(ctx, A, x, y); if (s2 != BIS_OK) return s2; }
+        hipEventRecord(e0, ctx->stream);
+        for (int i = 0; i < 5; ++i) { bis_status s2 = bis_spmv(ctx, A, x, y); if (s2 != BIS_OK) return s2; }
+        hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) return BIS_ERR_HIP;
+        float f = 0.f;
+        hipEventElapsedTime(&f, e0, e1);
+        ms = f / 5.0;
+        return BIS_OK;
+    };
+    // the streamed arrays: values, and the packed column stream (or the 32-bit columns)
+    struct Set { double *val; int32_t *col; uint16_t *pk; };
+    const int t = 1; // identical tables share stream 1 (bis_spmv.hip ensure_packed)
+    const bool packed = A->pk_state[t] == 1 && A->chunk_nnz == A->chunk_f;
+    const size_t n_val = (size_t)A->nnz + 8; // kPad
+    size_t n_pk = 0;
+    if (packed) {
+        int64_t ends[2];
+        hipMemcpyAsync(&ends[0], A->blkf_nnz, 8, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(&ends[1], A->blkf_nnz + A->n_blocks_f, 8, hipMemcpyDeviceToHost, ctx->stream);
+        hipStreamSynchronize(ctx->stream);
+        n_pk = (size_t)(ends[1] - A->pk_base[t]) + 16;
+    }
+    std::vector<Set> rejected;
+    double best = 0.0;
+    if (st == BIS_OK) st = measure(best);
+    if (first_ms) *first_ms = best;
+    for (int trial = 0; st == BIS_OK && trial < max_trials; ++trial) {
+        Set cand{nullptr, nullptr, nullptr};
+        hipError_t e = hipMalloc(&cand.val, sizeof(double) * n_val);
+        if (e == hipSuccess && packed) e = hipMalloc(&cand.pk, sizeof(uint16_t) * n_pk);
+        if (e == hipSuccess && !packed) e = hipMalloc(&cand.col, sizeof(int32_t) * n_val);
+        if (e != hipSuccess) { // out of memory: stop trying, keep what we have
+            hipFree(cand.val); hipFree(cand.pk); hipFree(cand.col);
+            (void)hipGetLastError();
+            break;
+        }
+        hipMemcpyAsync(cand.val, A->val, sizeof(double) * n_val, hipMemcpyDeviceToDevice, ctx->stream);
+        if (packed) hipMemcpyAsync(cand.pk, A->pk[t], sizeof(uint16_t) * n_pk, hipMemcpyDeviceToDevice, ctx->stream);
+        else hipMemcpyAsync(cand.col, A->col, sizeof(int32_t) * n_val, hipMemcpyDeviceToDevice, ctx->stream);
+        Set cur{A->val, packed ? nullptr : A->col, packed ? A->pk[t] : nullptr};
+        A->val = cand.val;
+        if (packed) A->pk[t] = cand.pk; else A->col = cand.col;
+        double ms = 0.0;
+        st = measure(ms);
+        if (st == BIS_OK && ms < best) {
+            best = ms;
+            rejected.push_back(cur);
+        } else {
+            A->val = cur.val;
+            if (packed) A->pk[t] = cur.pk; else A->col = cur.col;
+            rejected.push_back(cand);
+        }
+    }
+    hipStreamSynchronize(ctx->stream);
+    for (Set &r : rejected) { hipFree(r.val); hipFree(r.col); hipFree(r.pk); }
+    if (best_ms) *best_ms = best;
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    bis_vec_free(ctx, x);
+    bis_vec_free(ctx, y);
+    return st;
+}
+
 // debugging / tuning aid: device addresses of the CRS arrays
 BIS_API bis_status bis_mat_debug_ptrs(const bis_mat *A, void **row_ptr, void **col, void **val) {
     if (!A) return BIS_ERR_INVALID;

@@ -35,6 +35,8 @@ def run_distributed(args, rank, world, local_rank):
     N = n1 ** 3
     row_starts = even_row_starts(N, world, align=n1 * n1)
     row0, row1 = int(row_starts[rank]), int(row_starts[rank + 1])
+    if getattr(args, "tune_placement", 0) > 0:  # applied inside bis_dist_create, before the row views
+        ctx.lib.bis_set_option(b"tune_placement", int(args.tune_placement))
     A = ctx.gen_hpcg(n1, row0=row0, row1=row1)
     nnz_local = A.nnz
     d = Dist(ctx, A, rank, world, row_starts)

@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--size", type=int, default=256, help="HPCG grid edge (256 = metric size)")
     ap.add_argument("--precond", default="none", choices=["none", "j"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune-placement", type=int, default=0,
+                    help="setup: keep the fastest of K re-allocations of the matrix' streamed arrays "
+                         "(bis_mat_tune_placement; 0 = off)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0: sized for ~10-30 s")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "spmv_traffic.json"),
                     help="per-launch HBM bytes from the rocprofv3 PMC passes, if collected")
@@ -107,6 +110,10 @@ def main():
     N = n1 ** 3
     A = ctx.gen_hpcg(n1)
     nnz = A.nnz
+    tuned = None
+    if args.tune_placement > 0:  # untimed setup, a library feature (include/bis_hip.h)
+        f_ms, b_ms = ctx.tune_placement(A, args.tune_placement)
+        tuned = {"trials": args.tune_placement, "spmv_ms_first_allocation": f_ms, "spmv_ms_kept": b_ms}
     b, x = ctx.alloc(N), ctx.alloc(N)
     ctx.init_vector(b, 1.0)
     ctx.init_vector(x, 0.1)
@@ -171,6 +178,8 @@ def main():
         m = min(len(cpu_hist), len(hist))
         import numpy as np
         out["parity_max_dr_over_r0"] = float(np.max(np.abs(cpu_hist[:m] - hist[:m])) / cpu_hist[0])
+    if tuned:
+        out["placement_tuning"] = tuned
     print(json.dumps(out), flush=True)
     cg.free()
     ctx.close()

@@ -114,6 +114,16 @@ BIS_API bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows,
                                 int64_t *n_cols, int64_t *nnz);
 /* rebuild a matrix' row-block metadata after bis_set_option (tuning) */
 BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
+/* Placement tuning (setup, optional): WHERE in HBM the streamed arrays of a matrix
+ * land moves the SpMV time of the same data by up to 20 % (HPCG-256: 0.82 ... 0.98 ms
+ * between allocations of one process).  Re-allocates the
+ * streamed arrays (values and column stream) up to max_trials times, times the SpMV
+ * on each copy and keeps the fastest; the rejected copies are held until the end so
+ * that every trial sees different memory.  Transient memory: up to max_trials copies.
+ * Not for row views; call before views of A are made (bis_dist_create).
+ * first_ms / best_ms (optional): SpMV time before and after. */
+BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_trials,
+                                          double *first_ms, double *best_ms);
 /* device addresses of the CRS arrays (tuning / zero-copy interop) */
 BIS_API bis_status bis_mat_debug_ptrs(const bis_mat *A, void **row_ptr,
                                       void **col, void **val);

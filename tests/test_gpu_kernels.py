@@ -453,6 +453,29 @@ def test_device_multicolour_reordering(ctx, oracle, kind):
     assert relerr(dy.to_host(), oracle.spmv(A, x)[perm]) <= KTOL
 
 
+def test_tune_placement_keeps_the_matrix_intact(ctx, oracle):
+    """bis_mat_tune_placement re-allocates the streamed arrays: same SpMV result bit for bit, same
+    CRS download, for the packed stream and for the 32-bit column fallback."""
+    from basic_iterative_solvers_amd import load_library
+    lib = load_library()
+    A = oracle.gen_hpcg(24)
+    x = np.random.default_rng(11).uniform(-1, 1, A.n_rows)
+    for packed in (1, 0):
+        lib.bis_set_option(b"spmv_packed", packed)
+        dA = ctx.matrix(A)
+        dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
+        ctx.spmv(dA, dx, dy)
+        before = dy.to_host()
+        first, best = ctx.tune_placement(dA, 3)
+        assert 0 < best <= first
+        ctx.spmv(dA, dx, dy)
+        assert np.array_equal(dy.to_host(), before)
+        rp, col, val = dA.download()
+        assert np.array_equal(col, A.col) and np.array_equal(val, A.val)
+        dA.free()
+    lib.bis_set_option(b"spmv_packed", -1)
+
+
 def test_named_kernel_protocol(ctx, oracle):
     """The reference's plugin protocol (smax_helpers.hpp:7-42, kernels.hpp:48,
     cg.hpp:136-152, jacobi.hpp:93): register, run by name with an operand
