@@ -140,6 +140,16 @@ class Context:
         store.free()
         return Mat(self, h), perm, nc.value
 
+    def gather(self, out, vec, perm):
+        """out[i] = vec[perm[i]] on the device (perm: numpy int32, uploaded for the call)."""
+        n = len(perm)
+        raw = np.zeros((n + 1) // 2 + 1)
+        raw.view(np.int32)[:n] = np.asarray(perm, dtype=np.int32)
+        store = self.upload(raw)
+        self.check(self.lib.bis_vec_gather(self.h, C.c_void_p(out.ptr), C.c_void_p(vec.ptr), C.c_void_p(store.ptr), _i64(n)))
+        self.sync()
+        store.free()
+
     def tune_placement(self, A, max_trials=6):
         """Keep the fastest of up to max_trials re-allocations of A's streamed arrays; returns (first_ms, best_ms)."""
         f, b = C.c_double(), C.c_double()

@@ -453,6 +453,16 @@ def test_device_multicolour_reordering(ctx, oracle, kind):
     assert relerr(dy.to_host(), oracle.spmv(A, x)[perm]) <= KTOL
 
 
+def test_vec_gather(ctx):
+    rng = np.random.default_rng(21)
+    n = 1000
+    v = rng.uniform(-1, 1, n)
+    perm = rng.permutation(n).astype(np.int32)
+    dv, out = ctx.upload(v), ctx.alloc(n)
+    ctx.gather(out, dv, perm)
+    assert np.array_equal(out.to_host(), v[perm])
+
+
 def test_tune_placement_keeps_the_matrix_intact(ctx, oracle):
     """bis_mat_tune_placement re-allocates the streamed arrays: same SpMV result bit for bit, same
     CRS download, for the packed stream and for the 32-bit column fallback."""
