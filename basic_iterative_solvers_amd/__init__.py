@@ -140,6 +140,13 @@ class Context:
         store.free()
         return Mat(self, h), perm, nc.value
 
+    def scale_sym(self, A, init=0.0):
+        """-scale on the device: returns the scale vector s (Vec); A's values are scaled in place."""
+        s = self.alloc(A.n_rows)
+        self.init_vector(s, init)
+        self.check(self.lib.bis_mat_scale_sym(self.h, A.h, C.c_void_p(s.ptr)))
+        return s
+
     def gather(self, out, vec, perm):
         """out[i] = vec[perm[i]] on the device (perm: numpy int32, uploaded for the call)."""
         n = len(perm)

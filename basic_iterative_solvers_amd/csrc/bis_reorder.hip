@@ -260,6 +260,33 @@ __global__ __launch_bounds__(256) void gather_vec_kernel(const double *__restric
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[perm[i]];
 }
 
+// -scale on the device: extract_scale (utilities/LU_factors.hpp:880-898) + scale_mat
+// (preprocessing.hpp:15-24).  s_r = 1/sqrt(|a_rr|) (the last diagonal entry of the row wins,
+// rows without one keep the caller's value), then a_rc *= (s_r * s_c).
+template <typename RP>
+__global__ __launch_bounds__(256) void extract_scale_kernel(const RP *__restrict__ row_ptr,
+                                                            const int32_t *__restrict__ col,
+                                                            const double *__restrict__ val, int64_t n,
+                                                            double *__restrict__ s, unsigned long long *status) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k)
+        if (col[k] == r) {
+            const double v = val[k];
+            if (fabs(v) < 1e-16) atomicMin(status, (unsigned long long)(r + 1));
+            s[r] = 1.0 / sqrt(fabs(v));
+        }
+}
+template <typename RP>
+__global__ __launch_bounds__(256) void scale_mat_kernel(const RP *__restrict__ row_ptr,
+                                                        const int32_t *__restrict__ col, double *__restrict__ val,
+                                                        int64_t n, const double *__restrict__ s) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const double sr = s[r];
+    for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) val[k] *= (sr * s[col[k]]);
+}
+
 template <typename RP>
 bis_status multicolour_t(bis_ctx *ctx, const bis_mat *A, bis_mat **B_out, int32_t *perm_dev, int *n_colours_out) {
     const int64_t n = A->n_rows;
@@ -332,6 +359,36 @@ bis_status bis_mat_multicolour(bis_ctx *ctx, const bis_mat *A, bis_mat **B, int3
     return A->rp64 ? multicolour_t<int64_t>(ctx, A, B, perm_dev, n_colours)
                    : multicolour_t<int32_t>(ctx, A, B, perm_dev, n_colours);
 }
+
+
+bis_status bis_mat_scale_sym(bis_ctx *ctx, bis_mat *A, double *scale) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A && scale && !A->view && A->n_rows == A->n_cols, "bis_mat_scale_sym: bad arguments");
+    const int64_t n = A->n_rows;
+    if (n == 0) return BIS_OK;
+    unsigned long long *status = (unsigned long long *)(ctx->scalars_dev + 32);
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0xFF, 8, ctx->stream));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (A->rp64) {
+        hipLaunchKernelGGL(extract_scale_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->val, n, scale, status);
+        hipLaunchKernelGGL(scale_mat_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->val, n, scale);
+    } else {
+        hipLaunchKernelGGL(extract_scale_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->val, n, scale, status);
+        hipLaunchKernelGGL(scale_mat_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->val, n, scale);
+    }
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    unsigned long long h = 0;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h, status, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h != ~0ull) {
+        char msg[96];
+        snprintf(msg, sizeof msg, "Zero detected on diagonal at row index %lld", (long long)h - 1);
+        ctx->err = msg;
+        return BIS_ERR_ZERO_DIAG;
+    }
+    return BIS_OK;
+}
+
 
 bis_status bis_vec_gather(bis_ctx *ctx, double *out, const double *in, const int32_t *perm_dev, int64_t n) {
     BIS_CTX_OK(ctx);

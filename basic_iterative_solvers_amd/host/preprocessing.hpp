@@ -67,12 +67,19 @@ inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::u
 
     if (solver->num_scale) { // preprocessing.hpp:39-50: A' = D^-1/2 A D^-1/2, b' = D^-1/2 b
         const int N = solver->A->n_rows;
-        download_to_host(solver->A.get());
-        std::vector<double> s(N, 0.0);
-        extract_scale(solver->A.get(), s.data());
-        scale_mat(solver->A.get(), s.data());
-        solver->A->upload();
-        to_device(solver->A_D_scale, s.data(), N);
+        // extract_scale + scale_mat on the device (bis_mat_scale_sym); a matrix read from a file keeps its
+        // host copy in step so that later host-side steps (host reordering fallback) see the scaled values
+        init_vector(solver->A_D_scale, 0.0, N);
+        {
+            const bis_status sst = bis_mat_scale_sym(bis::ctx(), solver->A->dev, solver->A_D_scale);
+            if (sst == BIS_ERR_ZERO_DIAG) { fprintf(stderr, "%s\n", bis_last_error(bis::ctx())); exit(EXIT_FAILURE); }
+            bis::check(sst, "bis_mat_scale_sym");
+        }
+        if (solver->A->row_ptr) { // host copy present
+            std::vector<double> s(N, 0.0);
+            to_host(s.data(), solver->A_D_scale, N);
+            scale_mat(solver->A.get(), s.data());
+        }
         // the reference also scales x_0 here, after init_structs has already
         // copied the unscaled x_0 into the iterate; x_0 is not read again
         elemwise_mult_vectors(solver->x_0, solver->A_D_scale, solver->x_0, N);

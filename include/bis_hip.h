@@ -166,6 +166,14 @@ BIS_API bis_status bis_mat_split_strict(bis_ctx *ctx, const bis_mat *A,
                                         bis_mat **L_strict, bis_mat **U_strict,
                                         double *D, double *D_inv);
 
+/* -scale on the device: extract_scale
+ * (utilities/LU_factors.hpp:880-898), s_r = 1/sqrt(|a_rr|) written to scale[r]
+ * (rows without a diagonal entry keep the caller's value), then scale_mat
+ * (preprocessing.hpp:15-24), a_rc *= (s_r * s_c), in place.  BIS_ERR_ZERO_DIAG
+ * with the reference's message if |a_rr| < 1e-16.  The values only change, so
+ * the packed column stream and the row-block tables stay valid. */
+BIS_API bis_status bis_mat_scale_sym(bis_ctx *ctx, bis_mat *A, double *scale);
+
 /* Multi-colour symmetric reordering on the device (the
  * role of SMAX's permute_mat, utilities/smax_helpers.hpp:44-80): greedy
  * first-fit colouring in natural row order, rows grouped by colour (stable),

@@ -453,6 +453,26 @@ def test_device_multicolour_reordering(ctx, oracle, kind):
     assert relerr(dy.to_host(), oracle.spmv(A, x)[perm]) <= KTOL
 
 
+@pytest.mark.parametrize("name", GOLDEN_MATS)
+def test_device_scale_sym_bit_exact(ctx, oracle, name):
+    """-scale on the device (bis_mat_scale_sym) against extract_scale + scale_mat of the oracle:
+    scale vector and scaled values bit for bit; the SpMV on the scaled matrix (packed stream kept) agrees."""
+    A = crs_of(load_golden(name), "A")
+    dA = ctx.matrix(A)
+    s_dev = ctx.scale_sym(dA)
+    B = CRS(A.n_rows, A.row_ptr.copy(), A.col.copy(), A.val.copy())
+    s_ref, st = oracle.extract_scale(B)
+    assert st == 0
+    oracle.scale_mat(B, s_ref)
+    assert np.array_equal(s_dev.to_host(), s_ref)
+    rp, col, val = dA.download()
+    assert np.array_equal(val, B.val) and np.array_equal(col, B.col)
+    x = np.random.default_rng(2).uniform(-1, 1, A.n_rows)
+    dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
+    ctx.spmv(dA, dx, dy)
+    assert relerr(dy.to_host(), oracle.spmv(B, x)) <= KTOL
+
+
 def test_vec_gather(ctx):
     rng = np.random.default_rng(21)
     n = 1000
