@@ -188,6 +188,7 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_SPMV_PACKED")) v.spmv_packed = atoi(e);
         if (const char *e = getenv("BIS_SPMV_PACKED32")) v.spmv_packed32 = atoi(e);
         if (const char *e = getenv("BIS_TUNE_PLACEMENT")) v.tune_placement = atoi(e);
+        if (const char *e = getenv("BIS_CG_GRAPH")) v.cg_graph = atoi(e);
         return v;
     }();
     return o;
@@ -215,6 +216,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "spmv_lds_pad")) o.spmv_lds_pad = value;
     else if (!strcmp(name, "spmv_packed32")) o.spmv_packed32 = value;
     else if (!strcmp(name, "tune_placement")) o.tune_placement = value;
+    else if (!strcmp(name, "cg_graph")) o.cg_graph = value;
     else return BIS_ERR_INVALID;
     return BIS_OK;
 }

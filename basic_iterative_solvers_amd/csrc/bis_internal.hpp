@@ -66,6 +66,7 @@ struct bis_options {
     int trsv_batch = -1;   // dependencies polled per round trip (4, 8, 16; -1: by row length)
     int trsv_by_pos = -1;  // 1 (default): sentinel scratch in level order; 0: in row order
     int trsv_one_xcd = -1; // k > 0: sync-free sweeps run on one elected XCD with k workgroups per CU
+    int cg_graph = -1;      // 1: bis_cg_iterate replays one captured iteration as a hipGraph (opt-in, measured no gain)
     int tune_placement = -1; // k > 0: bis_dist_create runs bis_mat_tune_placement(A, k) before it makes the row views
     int spmv_packed32 = -1; // 1: also try the 32-window packed format (opt-in)
     int spmv_lds_pad = -1; // diagnostic: extra dynamic LDS bytes per workgroup (lowers occupancy)
