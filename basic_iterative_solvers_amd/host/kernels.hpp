@@ -9,16 +9,29 @@
 #include "common.hpp"
 #include "sparse_matrix.hpp"
 
+// The reference brackets its three sparse kernels with LIKWID markers ("spmv", "sptrsv",
+// "backwards-sptrsv": kernels.hpp:25-39, :56-74, :90-105); here the same names are roctx ranges
+// (rocprofv3 --marker-trace), around the enqueue of the device kernels.
+#ifdef USE_ROCTX
+#include <roctracer/roctx.h>
+struct MarkerRange { explicit MarkerRange(const char *n) { roctxRangePushA(n); } ~MarkerRange() { roctxRangePop(); } };
+#else
+struct MarkerRange { explicit MarkerRange(const char *) {} };
+#endif
+
 inline void spmv(const MatrixCRS *A, const double *x, double *y, int = 0, Interface * = nullptr,
                  const std::string = "") {
+    MarkerRange m("spmv");
     bis::check(bis_spmv(bis::ctx(), A->dev, x, y), "spmv");
 }
 inline void sptrsv(const MatrixCRS *L, double *x, const double *D, const double *b, int = 0,
                    Interface * = nullptr, const std::string = "") {
+    MarkerRange m("sptrsv");
     bis::check(bis_sptrsv(bis::ctx(), L->dev, x, D, b), "sptrsv");
 }
 inline void bsptrsv(const MatrixCRS *U, double *x, const double *D, const double *b, int = 0,
                     Interface * = nullptr, const std::string = "") {
+    MarkerRange m("backwards-sptrsv");
     bis::check(bis_bsptrsv(bis::ctx(), U->dev, x, D, b), "bsptrsv");
 }
 inline void subtract_vectors(double *r, const double *a, const double *b, const int N, const double scale = 1.0) {

@@ -132,8 +132,27 @@ inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::u
         bis::check(bis_vec_free(bis::ctx(), perm_store), "bis_vec_free");
         if (!cli_args->dump_perm.empty()) write_permutation(cli_args->dump_perm, perm);
         std::cout << "multi-colour reordering: " << n_colours << " colours" << std::endl;
+    } else if (cli_args->perm_mode == "rcm" || cli_args->perm_mode == "bfs") {
+        // bandwidth-reducing orderings (host, setup only): they keep the sweeps level-scheduled, with
+        // fewer or more levels than the natural order depending on the input
+        const int N = solver->A->n_rows;
+        download_to_host(solver->A.get());
+        std::vector<int> perm, inv_perm;
+        bfs_like_permutation(solver->A.get(), cli_args->perm_mode == "rcm", perm, inv_perm);
+        auto B = std::make_unique<MatrixCRS>();
+        permute_matrix(solver->A.get(), perm, inv_perm, B.get());
+        B->upload();
+        solver->A = std::move(B);
+        if (solver->num_scale) {
+            std::vector<double> hb(N), pb(N);
+            to_host(hb.data(), solver->b, N);
+            for (int i = 0; i < N; ++i) pb[i] = hb[perm[i]];
+            to_device(solver->b, pb.data(), N);
+        }
+        if (!cli_args->dump_perm.empty()) write_permutation(cli_args->dump_perm, perm);
+        std::cout << (cli_args->perm_mode == "rcm" ? "reverse Cuthill-McKee" : "breadth-first") << " reordering" << std::endl;
     } else if (cli_args->perm_mode != "none") {
-        fprintf(stderr, "ERROR: unknown -perm mode (available: mc)\n");
+        fprintf(stderr, "ERROR: unknown -perm mode (available: mc, rcm, bfs)\n");
         exit(EXIT_FAILURE);
     }
 

@@ -61,6 +61,7 @@ inline void parse_cli(Args *a, int argc, char *argv[]) {
         else if (arg == "-perm" && i + 1 < argc) a->perm_mode = argv[++i];
         else if (arg == "-dump-perm" && i + 1 < argc) a->dump_perm = argv[++i];
         else if (arg == "-perm-host") a->perm_host = true;
+        else if (arg == "-cache" && i + 1 < argc) a->crs_cache = argv[++i];
         else if (arg == "-dev" && i + 1 < argc) a->device = atoi(argv[++i]);
         else std::cout << "ERROR: assign_cli_inputs: Arguement \"" << arg << "\" not recongnized." << std::endl;
     }
@@ -116,6 +117,35 @@ inline void convert_coo_to_crs(MatrixCOO *coo, MatrixCRS *crs) {
     for (int k = 0; k < crs->nnz; ++k) { crs->col[k] = coo->J[k]; crs->val[k] = coo->values[k]; ++crs->row_ptr[coo->I[k] + 1]; }
     for (int r = 0; r < crs->n_rows; ++r) crs->row_ptr[r + 1] += crs->row_ptr[r];
     if (crs->row_ptr[crs->n_rows] != crs->nnz) { printf("ERROR: converting to CRS.\n"); exit(1); }
+}
+
+// Binary CRS cache of a parsed .mtx input: header {magic, n_rows, n_cols, nnz}
+// as int64, then row_ptr (int32[n_rows+1]), col (int32[nnz]), val (double[nnz]) exactly as
+// convert_coo_to_crs produced them, so a cached run sees the same matrix bit for bit.
+inline bool read_crs_cache(const std::string &path, MatrixCRS *A) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    long long h[4] = {0, 0, 0, 0};
+    bool ok = fread(h, sizeof(long long), 4, f) == 4 && h[0] == 0x4253435253ll && h[1] >= 0 && h[3] >= 0;
+    if (ok) {
+        MatrixCRS tmp((std::size_t)h[1], (std::size_t)h[2], (std::size_t)h[3]);
+        ok = fread(tmp.row_ptr, sizeof(int), (size_t)h[1] + 1, f) == (size_t)h[1] + 1 &&
+             fread(tmp.col, sizeof(int), (size_t)h[3], f) == (size_t)h[3] &&
+             fread(tmp.val, sizeof(double), (size_t)h[3], f) == (size_t)h[3];
+        if (ok) *A = tmp;
+    }
+    fclose(f);
+    return ok;
+}
+inline void write_crs_cache(const std::string &path, const MatrixCRS *A) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { fprintf(stderr, "WARNING: cannot write the CRS cache %s\n", path.c_str()); return; }
+    const long long h[4] = {0x4253435253ll, A->n_rows, A->n_cols, A->nnz};
+    fwrite(h, sizeof(long long), 4, f);
+    fwrite(A->row_ptr, sizeof(int), (size_t)A->n_rows + 1, f);
+    fwrite(A->col, sizeof(int), (size_t)A->nnz, f);
+    fwrite(A->val, sizeof(double), (size_t)A->nnz, f);
+    fclose(f);
 }
 
 // generator strings -> device-resident matrix (no host copy)

@@ -152,3 +152,55 @@ def test_cli_device_and_host_reordering_agree(tmp_path, name, solver, pc, scale)
     assert np.array_equal(np.loadtxt(f1, dtype=np.int64), np.loadtxt(f2, dtype=np.int64))
     assert a["iters"] == b["iters"] and len(a["hist"]) == len(b["hist"])
     assert np.max(np.abs(a["hist"] - b["hist"])) <= 1e-12 * a["hist"][0]
+
+
+@pytest.mark.parametrize("mode,name,solver,pc", [("rcm", "FDM-2d-16", "cg", "sgs"), ("bfs", "matrix_band_klein", "gs", "none"),
+                                                 ("rcm", "hpcg_4x6x5", "gm", "gs"), ("bfs", "anderson8_shift9", "bi", "ilu0")])
+def test_cli_rcm_bfs_reordering_vs_oracle_on_permuted_matrix(tmp_path, oracle, mode, name, solver, pc):
+    """-perm rcm / -perm bfs (SMAX PERM_MODE roles): any valid permutation is accepted; the parity
+    target is the reference algorithm (oracle) on the same permuted matrix P A P^T."""
+    from helpers import crs_of, load_golden
+    from oracle.pyoracle import CRS
+    permfile = str(tmp_path / "perm.txt")
+    kw = {"restart_len": 50} if solver == "gm" else {}
+    r = run_cli(name, solver, pc, kw, extra=["-perm", mode, "-dump-perm", permfile])
+    perm = np.loadtxt(permfile, dtype=np.int64)
+    A = crs_of(load_golden(name), "A")
+    n = A.n_rows
+    assert sorted(perm) == list(range(n))
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    lens = np.diff(A.row_ptr)[perm]
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    col = np.concatenate([inv[A.col[A.row_ptr[o]:A.row_ptr[o + 1]]] for o in perm]).astype(np.int32)
+    val = np.concatenate([A.val[A.row_ptr[o]:A.row_ptr[o + 1]] for o in perm])
+    B = CRS(n, rp, col, val)
+    if mode == "rcm":  # the point of RCM: the bandwidth does not grow on these banded inputs
+        bw = lambda M: max(abs(int(c) - r_) for r_ in range(M.n_rows) for c in M.col[M.row_ptr[r_]:M.row_ptr[r_ + 1]])
+        assert bw(B) <= bw(A) * 2
+    o = oracle.solve(B, solver, pc, ilu_real=True, **kw)
+    e = dict(hist=[float(v) for v in o["hist"]], iters=o["iters"], converged=o["converged"])
+    check_history(r, e, solver)
+    if solver != "bi":
+        assert abs(r["iters"] - o["iters"]) <= 1
+
+
+def test_cli_binary_crs_cache(tmp_path):
+    """-cache FILE: the first run parses the .mtx and writes the binary CRS, the second reads it;
+    identical residual tables."""
+    cache = str(tmp_path / "fdm.crs")
+    a = run_cli("FDM-2d-16", "cg", "j", {}, extra=["-cache", cache])
+    assert os.path.getsize(cache) > 1000
+    b = run_cli("FDM-2d-16", "cg", "j", {}, extra=["-cache", cache])
+    assert np.array_equal(a["hist"], b["hist"]) and a["iters"] == b["iters"]
+    # a cache file that is not one is ignored (falls back to the parser)
+    with open(cache, "wb") as f:
+        f.write(b"not a cache")
+    c = run_cli("FDM-2d-16", "cg", "j", {}, extra=["-cache", cache])
+    assert np.array_equal(a["hist"], c["hist"])
+
+
+def test_cli_is_linked_with_roctx():
+    """The reference's LIKWID markers around spmv / sptrsv / backwards-sptrsv are roctx ranges here."""
+    out = subprocess.run(["ldd", BIN], capture_output=True, text=True)
+    assert "libroctx64" in out.stdout, out.stdout
