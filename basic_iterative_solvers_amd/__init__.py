@@ -66,6 +66,10 @@ class Context:
     def sync(self):
         self.check(self.lib.bis_sync(self.h))
 
+    def set_option(self, name, value):
+        if self.lib.bis_set_option(name.encode(), C.c_int(int(value))) != 0:
+            raise BisError(f"bis_set_option: unknown option {name}")
+
     def device_info(self):
         arch = C.create_string_buffer(64)
         n_cus = C.c_int()
@@ -170,6 +174,12 @@ class Context:
         self.check(self.lib.bis_mat_split_strict(self.h, A.h, C.byref(hl), C.byref(hu),
                                                  C.c_void_p(D.ptr), C.c_void_p(Dinv.ptr)))
         return Mat(self, hl), Mat(self, hu), D, Dinv
+
+    def mat_diag(self, A, row_offset=0):
+        """(D, 1/D) of a row block with global column indices (bis_mat_diag)."""
+        D, Dinv = self.alloc(A.n_rows), self.alloc(A.n_rows)
+        self.check(self.lib.bis_mat_diag(self.h, A.h, _i64(row_offset), C.c_void_p(D.ptr), C.c_void_p(Dinv.ptr)))
+        return D, Dinv
 
     def ilu0(self, A, pivot_tol=1e-8, pivot_repl=1e-4):
         n = A.n_rows
@@ -307,6 +317,10 @@ class Mat:
         ctx.lib.bis_mat_info(h, C.byref(n_rows), C.byref(n_cols), C.byref(nnz))
         self.n_rows, self.n_cols, self.nnz = n_rows.value, n_cols.value, nnz.value
 
+    @property
+    def rp_width(self):
+        return int(self.ctx.lib.bis_mat_rp_width(self.h))
+
     def download(self):
         rp = np.zeros(self.n_rows + 1, dtype=np.int64)
         col = np.zeros(self.nnz, dtype=np.int32)
@@ -428,6 +442,20 @@ class Dist:
                                                  C.c_void_p(b.ptr), C.c_void_p(dev.ptr), C.byref(out)))
         dev.free()
         return out.value
+
+    def stats(self):
+        nh, ns, ni = C.c_int64(), C.c_int64(), C.c_int64()
+        nn, nr = C.c_int(), C.c_int()
+        self.ctx.lib.bis_dist_stats(self.h, C.byref(nh), C.byref(ns), C.byref(ni), C.byref(nn), C.byref(nr))
+        return dict(halo_entries=nh.value, send_entries=ns.value, halo_bytes_per_spmv=8 * (nh.value + ns.value),
+                    interior_rows=ni.value, neighbours=nn.value, rccl_ranks_seen=nr.value)
+
+    def profile_read(self):
+        ne, na = C.c_int64(), C.c_int64()
+        te, ta = C.c_double(), C.c_double()
+        self.ctx.check(self.ctx.lib.bis_dist_profile_read(self.ctx.h, self.h, C.byref(ne), C.byref(te),
+                                                          C.byref(na), C.byref(ta)))
+        return dict(exchanges=ne.value, exchange_ms=te.value, allreduces=na.value, allreduce_ms=ta.value)
 
     def cg(self, b, x, A_D=None):
         cg = CG.__new__(CG)

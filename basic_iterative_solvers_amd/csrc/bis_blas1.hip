@@ -173,6 +173,16 @@ bis_status bis_ensure_partials(bis_ctx *ctx, size_t n) {
     return BIS_OK;
 }
 
+bis_status bis_fault_check(bis_ctx *ctx) {
+    volatile unsigned *f = ctx->fault_host;
+    if (!f || *f == 0) return BIS_OK;
+    *f = 0; // reported once
+    ctx->err = "a triangular sweep lost a hand-off: a row waited for a result that was never published "
+               "(a workgroup of the persistent grid could not become resident, or the dependency data is corrupt); "
+               "the vectors written since the last blocking call are invalid";
+    return BIS_ERR_SYNC;
+}
+
 bis_options &bis_opts() {
     static bis_options o = [] {
         bis_options v;
@@ -189,6 +199,7 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_SPMV_PACKED32")) v.spmv_packed32 = atoi(e);
         if (const char *e = getenv("BIS_TUNE_PLACEMENT")) v.tune_placement = atoi(e);
         if (const char *e = getenv("BIS_CG_GRAPH")) v.cg_graph = atoi(e);
+        if (const char *e = getenv("BIS_FORCE_RP64")) v.force_rp64 = atoi(e);
         return v;
     }();
     return o;
@@ -217,6 +228,9 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "spmv_packed32")) o.spmv_packed32 = value;
     else if (!strcmp(name, "tune_placement")) o.tune_placement = value;
     else if (!strcmp(name, "cg_graph")) o.cg_graph = value;
+    else if (!strcmp(name, "force_rp64")) o.force_rp64 = value;
+    else if (!strcmp(name, "dist_host_plan")) o.dist_host_plan = value;
+    else if (!strcmp(name, "trsv_inject_loss")) o.trsv_inject_loss = value;
     else return BIS_ERR_INVALID;
     return BIS_OK;
 }
@@ -259,7 +273,10 @@ bis_status bis_ctx_create(int device, void *stream, bis_ctx **out) {
               hipHostMalloc(&ctx->scalars_host, sizeof(double) * 64) == hipSuccess &&
               hipMalloc(&ctx->counters, sizeof(unsigned) * 64) == hipSuccess &&
               hipMemset(ctx->counters, 0, sizeof(unsigned) * 64) == hipSuccess &&
-              hipMemset(ctx->scalars_dev, 0, sizeof(double) * 64) == hipSuccess;
+              hipMemset(ctx->scalars_dev, 0, sizeof(double) * 64) == hipSuccess &&
+              hipHostMalloc(&ctx->fault_host, sizeof(unsigned) * 16, hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&ctx->fault_dev, ctx->fault_host, 0) == hipSuccess;
+    if (ok) memset(ctx->fault_host, 0, sizeof(unsigned) * 16);
     if (!ok) {
         delete ctx;
         return BIS_ERR_HIP;
@@ -276,6 +293,7 @@ bis_status bis_ctx_destroy(bis_ctx *ctx) {
     hipFree(ctx->scalars_dev);
     hipHostFree(ctx->scalars_host);
     hipFree(ctx->counters);
+    hipHostFree(ctx->fault_host);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return BIS_OK;
@@ -285,7 +303,7 @@ const char *bis_last_error(const bis_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 bis_status bis_sync(bis_ctx *ctx) {
     BIS_CTX_OK(ctx);
-    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    BIS_SYNC_CHECK(ctx);
     return BIS_OK;
 }
 
@@ -337,7 +355,7 @@ bis_status bis_vec_download(bis_ctx *ctx, double *dst, const double *src, int64_
     if (n == 0) return BIS_OK;
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
                                       ctx->stream));
-    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    BIS_SYNC_CHECK(ctx);
     return BIS_OK;
 }
 
@@ -470,7 +488,7 @@ bis_status bis_dot(bis_ctx *ctx, const double *a, const double *b, int64_t n,
     if (st != BIS_OK) return st;
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(ctx->scalars_host, ctx->scalars_dev, sizeof(double),
                                       hipMemcpyDeviceToHost, ctx->stream));
-    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    BIS_SYNC_CHECK(ctx);
     *result_host = ctx->scalars_host[0];
     return BIS_OK;
 }

@@ -409,7 +409,7 @@ bis_status bis_cg_status(bis_ctx *ctx, bis_cg *cg, int *iters, int *converged, d
     BIS_REQUIRE(ctx, cg, "bis_cg_status: null handle");
     int flags[4] = {0, 0, 0, 0};
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(flags, cg->flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
-    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    BIS_SYNC_CHECK(ctx);
     if (iters) *iters = flags[0];
     if (converged) *converged = flags[2];
     if (hist_host && hist_cap > 0) {

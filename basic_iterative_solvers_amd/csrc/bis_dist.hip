@@ -35,6 +35,16 @@ struct bis_dist {
     bool have_ops = false;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+    // HIP-event timing of the two exchange shapes while bis_profile_enable is on (bis_dist_profile_read)
+    struct EvPool {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+        size_t used = 0;
+        std::pair<hipEvent_t, hipEvent_t> &next() {
+            if (used == ev.size()) { hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); ev.emplace_back(a, b); }
+            return ev[used++];
+        }
+        void destroy() { for (auto &p : ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); } ev.clear(); used = 0; }
+    } prof_exchange, prof_allreduce;
     // RCCL backend state
     void *rccl_lib = nullptr;
     ncclComm_t comm = nullptr;
@@ -42,6 +52,7 @@ struct bis_dist {
         ncclResult_t (*GetUniqueId)(ncclUniqueId *);
         ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
         ncclResult_t (*CommDestroy)(ncclComm_t);
+        ncclResult_t (*CommCount)(const ncclComm_t, int *);
         ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
         ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
         ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
@@ -79,6 +90,176 @@ __global__ __launch_bounds__(256) void pack_kernel(const double *x, const int32_
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = x[idx[i]];
 }
 
+// ---- halo plan on the device: only what the plan needs leaves HBM ---------------------------------
+// count pass: per row the number of remote entries (column outside [row0,row1)); per 256-row block
+// the number of remote entries and of boundary rows (rows with at least one).
+template <typename RP>
+__global__ __launch_bounds__(256) void plan_count_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                         int64_t n_rows, int64_t row0, int64_t row1,
+                                                         int64_t *__restrict__ blk_ent, int64_t *__restrict__ blk_row) {
+    __shared__ double lds[4];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int cnt = 0;
+    if (r < n_rows)
+        for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) {
+            const int64_t c = col[k];
+            cnt += (c < row0 || c >= row1);
+        }
+    const double se = block_sum<256>((double)cnt, lds); // exact: counts < 2^53
+    __syncthreads();
+    const double sr = block_sum<256>(cnt > 0 ? 1.0 : 0.0, lds);
+    if (threadIdx.x == 0) { blk_ent[blockIdx.x] = (int64_t)se; blk_row[blockIdx.x] = (int64_t)sr; }
+}
+
+// exclusive scan of the two block-sum arrays by one workgroup; totals to out2
+__global__ __launch_bounds__(256) void plan_scan_kernel(int64_t *a, int64_t *b, int n_blk, int64_t *out2) {
+    __shared__ int64_t sa[256], sb[256];
+    int64_t run_a = 0, run_b = 0;
+    for (int base = 0; base < n_blk; base += 256) {
+        const int i = base + threadIdx.x;
+        const int64_t va = i < n_blk ? a[i] : 0, vb = i < n_blk ? b[i] : 0;
+        sa[threadIdx.x] = va;
+        sb[threadIdx.x] = vb;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int64_t xa = 0, xb = 0;
+            if ((int)threadIdx.x >= off) { xa = sa[threadIdx.x - off]; xb = sb[threadIdx.x - off]; }
+            __syncthreads();
+            sa[threadIdx.x] += xa;
+            sb[threadIdx.x] += xb;
+            __syncthreads();
+        }
+        if (i < n_blk) { a[i] = run_a + sa[threadIdx.x] - va; b[i] = run_b + sb[threadIdx.x] - vb; }
+        run_a += sa[255];
+        run_b += sb[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = run_a; out2[1] = run_b; }
+}
+
+// fill pass: the remote columns (row order, duplicates kept) and the boundary rows (ascending)
+template <typename RP>
+__global__ __launch_bounds__(256) void plan_fill_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                        int64_t n_rows, int64_t row0, int64_t row1,
+                                                        const int64_t *__restrict__ blk_ent, const int64_t *__restrict__ blk_row,
+                                                        int32_t *__restrict__ out_cols, int32_t *__restrict__ out_rows) {
+    __shared__ int64_t se[256], sr[256];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int cnt = 0;
+    if (r < n_rows)
+        for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) {
+            const int64_t c = col[k];
+            cnt += (c < row0 || c >= row1);
+        }
+    se[threadIdx.x] = cnt;
+    sr[threadIdx.x] = cnt > 0;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int64_t xa = 0, xb = 0;
+        if ((int)threadIdx.x >= off) { xa = se[threadIdx.x - off]; xb = sr[threadIdx.x - off]; }
+        __syncthreads();
+        se[threadIdx.x] += xa;
+        sr[threadIdx.x] += xb;
+        __syncthreads();
+    }
+    if (r >= n_rows || cnt == 0) return;
+    int64_t pe = blk_ent[blockIdx.x] + se[threadIdx.x] - cnt;
+    out_rows[blk_row[blockIdx.x] + sr[threadIdx.x] - 1] = (int32_t)r;
+    for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) {
+        const int64_t c = col[k];
+        if (c < row0 || c >= row1) out_cols[pe++] = (int32_t)c;
+    }
+}
+
+// D[r] = a(r, row_offset + r): the diagonal of a row block with GLOBAL column indices (peel_diag_crs
+// semantics, utilities/LU_factors.hpp:827-869: the last diagonal entry of a row wins; zero / missing
+// diagonals are reported through the status word like bis_mat_split_strict)
+template <typename RP>
+__global__ __launch_bounds__(256) void diag_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                   const double *__restrict__ val, int64_t n_rows, int64_t row_offset,
+                                                   double *D, double *D_inv, unsigned long long *status) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t g = row_offset + r;
+    bool have = false;
+    for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k)
+        if ((int64_t)col[k] == g) {
+            const double v = val[k];
+            have = true;
+            D[r] = v;
+            if (D_inv) D_inv[r] = 1.0 / v;
+            if (fabs(v) < 1e-16) atomicMin(status, ((unsigned long long)(g + 1) << 1) | 0ull);
+        }
+    if (!have) atomicMin(status, ((unsigned long long)(g + 1) << 1) | 1ull);
+}
+
+// Device version of bis_halo_plan: same outputs (sorted distinct remote columns, per-owner counts,
+// longest interior row run) from the remote entries and boundary rows alone -- a z-slab of HPCG-512 / 8
+// ships 2 x 512^2 x 9 column indices and 2 x 512^2 row indices instead of 1.8 GB of CRS structure.
+bis_status device_halo_plan(bis_ctx *ctx, const bis_mat *A, int n_ranks, const int64_t *row_starts, int64_t row0,
+                            int64_t row1, std::vector<int32_t> &halo, std::vector<int64_t> &recv_counts,
+                            int64_t interior[2]) {
+    const int64_t n = A->n_rows;
+    const int n_blk = (int)((n + 255) / 256);
+    halo.clear();
+    recv_counts.assign(n_ranks, 0);
+    interior[0] = 0; interior[1] = n;
+    if (n_blk == 0) return BIS_OK;
+    int64_t *blk = nullptr;
+    BIS_HIP_CHECK(ctx, hipMalloc(&blk, sizeof(int64_t) * (size_t)(2 * n_blk + 2)));
+    int64_t *blk_ent = blk, *blk_row = blk + n_blk, *tot = blk + 2 * n_blk;
+    if (A->rp64)
+        hipLaunchKernelGGL(plan_count_kernel<int64_t>, dim3(n_blk), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr,
+                           A->col, n, row0, row1, blk_ent, blk_row);
+    else
+        hipLaunchKernelGGL(plan_count_kernel<int32_t>, dim3(n_blk), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr,
+                           A->col, n, row0, row1, blk_ent, blk_row);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, blk_ent, blk_row, n_blk, tot);
+    int64_t h_tot[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(h_tot, tot, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { hipFree(blk); ctx->err = std::string("halo plan: ") + hipGetErrorString(e); return BIS_ERR_HIP; }
+    std::vector<int32_t> ent((size_t)h_tot[0]), rows((size_t)h_tot[1]);
+    if (h_tot[0] > 0) {
+        int32_t *d_ent = nullptr, *d_rows = nullptr;
+        e = hipMalloc(&d_ent, sizeof(int32_t) * (size_t)h_tot[0]);
+        if (e == hipSuccess) e = hipMalloc(&d_rows, sizeof(int32_t) * (size_t)h_tot[1]);
+        if (e == hipSuccess) {
+            if (A->rp64)
+                hipLaunchKernelGGL(plan_fill_kernel<int64_t>, dim3(n_blk), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr,
+                                   A->col, n, row0, row1, blk_ent, blk_row, d_ent, d_rows);
+            else
+                hipLaunchKernelGGL(plan_fill_kernel<int32_t>, dim3(n_blk), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr,
+                                   A->col, n, row0, row1, blk_ent, blk_row, d_ent, d_rows);
+            e = hipMemcpyAsync(ent.data(), d_ent, sizeof(int32_t) * ent.size(), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(rows.data(), d_rows, sizeof(int32_t) * rows.size(), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        hipFree(d_ent);
+        hipFree(d_rows);
+    }
+    hipFree(blk);
+    if (e != hipSuccess) { ctx->err = std::string("halo plan: ") + hipGetErrorString(e); return BIS_ERR_HIP; }
+    std::sort(ent.begin(), ent.end());
+    ent.erase(std::unique(ent.begin(), ent.end()), ent.end());
+    int p = 0;
+    for (int32_t c : ent) {
+        while (p < n_ranks - 1 && c >= row_starts[p + 1]) ++p;
+        if (c < row_starts[p] || c >= row_starts[p + 1]) { ctx->err = "bis_dist_create: column outside the global range"; return BIS_ERR_INVALID; }
+        recv_counts[p]++;
+    }
+    halo.swap(ent);
+    // longest run of rows without a remote column (same tie-breaking as bis_halo_plan: the first longest run)
+    int64_t best_a = 0, best_b = 0, run_a = 0;
+    for (int32_t r : rows) {
+        if (r - run_a > best_b - best_a) { best_a = run_a; best_b = r; }
+        run_a = (int64_t)r + 1;
+    }
+    if (n - run_a > best_b - best_a) { best_a = run_a; best_b = n; }
+    interior[0] = best_a; interior[1] = best_b;
+    return BIS_OK;
+}
+
 void *load_rccl() {
     // prefer a copy that is already mapped (torch ships its own librccl.so);
     // never mix two RCCL instances in one process
@@ -101,7 +282,7 @@ bool bind_rccl(bis_dist *d) {
     if (!h) return false;
     bool ok = sym(h, "ncclGetUniqueId", d->nccl.GetUniqueId) &&
               sym(h, "ncclCommInitRank", d->nccl.CommInitRank) &&
-              sym(h, "ncclCommDestroy", d->nccl.CommDestroy) &&
+              sym(h, "ncclCommDestroy", d->nccl.CommDestroy) && sym(h, "ncclCommCount", d->nccl.CommCount) &&
               sym(h, "ncclAllReduce", d->nccl.AllReduce) && sym(h, "ncclSend", d->nccl.Send) &&
               sym(h, "ncclRecv", d->nccl.Recv) && sym(h, "ncclGroupStart", d->nccl.GroupStart) &&
               sym(h, "ncclGroupEnd", d->nccl.GroupEnd) &&
@@ -179,6 +360,33 @@ bis_status bis_halo_plan(int64_t n_local, const int64_t *row_ptr, const int32_t 
     return BIS_OK;
 }
 
+bis_status bis_mat_diag(bis_ctx *ctx, const bis_mat *A, int64_t row_offset, double *D, double *D_inv) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A && D && row_offset >= 0, "bis_mat_diag: bad arguments");
+    if (A->n_rows == 0) return BIS_OK;
+    unsigned long long *status = (unsigned long long *)(ctx->scalars_dev + 34);
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0xFF, 8, ctx->stream));
+    const unsigned grid = (unsigned)((A->n_rows + 255) / 256);
+    if (A->rp64)
+        hipLaunchKernelGGL(diag_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col,
+                           A->val, A->n_rows, row_offset, D, D_inv, status);
+    else
+        hipLaunchKernelGGL(diag_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col,
+                           A->val, A->n_rows, row_offset, D, D_inv, status);
+    unsigned long long h = 0;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h, status, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h != ~0ull) {
+        char msg[128];
+        const bool missing = h & 1ull;
+        snprintf(msg, sizeof msg, missing ? "No diagonal to extract at row index %lld" : "Zero detected on diagonal at row index %lld",
+                 (long long)(h >> 1) - 1);
+        ctx->err = msg;
+        return missing ? BIS_ERR_NO_DIAG : BIS_ERR_ZERO_DIAG;
+    }
+    return BIS_OK;
+}
+
 bis_status bis_dist_create(bis_ctx *ctx, bis_mat *A, int rank, int n_ranks, const int64_t *row_starts,
                            bis_dist **out) {
     BIS_CTX_OK(ctx);
@@ -197,20 +405,27 @@ bis_status bis_dist_create(bis_ctx *ctx, bis_mat *A, int rank, int n_ranks, cons
     d->row_starts.assign(row_starts, row_starts + n_ranks + 1);
     d->recv_counts.assign(n_ranks, 0);
     d->send_counts.assign(n_ranks, 0);
-    // plan on the host from the downloaded structure
-    std::vector<int64_t> rp(A->n_rows + 1);
-    std::vector<int32_t> col((size_t)std::max<int64_t>(A->nnz, 1));
-    bis_status st = bis_mat_download(ctx, A, rp.data(), col.data(), nullptr);
+    // plan: on the device (only the remote entries and the boundary rows are downloaded); the host planner
+    // (bis_halo_plan on the downloaded structure) stays selectable for cross-checks (dist_host_plan=1)
     int64_t interior[2] = {0, 0};
-    if (st == BIS_OK) {
-        st = bis_halo_plan(A->n_rows, rp.data(), col.data(), n_ranks, rank, row_starts, &d->n_halo,
-                           nullptr, 0, d->recv_counts.data(), interior);
+    bis_status st;
+    if (bis_opts().dist_host_plan > 0) {
+        std::vector<int64_t> rp(A->n_rows + 1);
+        std::vector<int32_t> col((size_t)std::max<int64_t>(A->nnz, 1));
+        st = bis_mat_download(ctx, A, rp.data(), col.data(), nullptr);
         if (st == BIS_OK) {
-            d->halo_cols.resize((size_t)d->n_halo);
             st = bis_halo_plan(A->n_rows, rp.data(), col.data(), n_ranks, rank, row_starts, &d->n_halo,
-                               d->halo_cols.data(), d->n_halo, d->recv_counts.data(), interior);
+                               nullptr, 0, d->recv_counts.data(), interior);
+            if (st == BIS_OK) {
+                d->halo_cols.resize((size_t)d->n_halo);
+                st = bis_halo_plan(A->n_rows, rp.data(), col.data(), n_ranks, rank, row_starts, &d->n_halo,
+                                   d->halo_cols.data(), d->n_halo, d->recv_counts.data(), interior);
+            }
+            if (st != BIS_OK) ctx->err = "bis_dist_create: halo planning failed (column outside the global range?)";
         }
-        if (st != BIS_OK) ctx->err = "bis_dist_create: halo planning failed (column outside the global range?)";
+    } else {
+        st = device_halo_plan(ctx, A, n_ranks, row_starts, row0, row1, d->halo_cols, d->recv_counts, interior);
+        d->n_halo = (int64_t)d->halo_cols.size();
     }
     if (st != BIS_OK) { delete d; return st; }
     // renumber the columns on the device
@@ -268,7 +483,46 @@ bis_status bis_dist_destroy(bis_ctx *ctx, bis_dist *d) {
     if (d->ev_packed) hipEventDestroy(d->ev_packed);
     if (d->ev_halo) hipEventDestroy(d->ev_halo);
     if (d->comm_stream) hipStreamDestroy(d->comm_stream);
+    d->prof_exchange.destroy();
+    d->prof_allreduce.destroy();
     delete d;
+    return BIS_OK;
+}
+
+bis_status bis_dist_stats(const bis_dist *d, int64_t *n_halo, int64_t *n_send, int64_t *interior_rows,
+                          int *n_neighbours, int *rccl_ranks) {
+    if (d && rccl_ranks) {
+        int k = 0;
+        if (d->comm && d->nccl.CommCount && d->nccl.CommCount(d->comm, &k) != ncclSuccess) k = -1;
+        *rccl_ranks = k; // 0: the transport is not the native RCCL one
+    }
+    if (!d) return BIS_ERR_INVALID;
+    if (n_halo) *n_halo = d->n_halo;
+    if (n_send) *n_send = d->n_send;
+    if (interior_rows) *interior_rows = d->mid_b - d->mid_a;
+    if (n_neighbours) {
+        int k = 0;
+        for (int p = 0; p < d->n_ranks; ++p) k += (d->recv_counts[p] > 0 || d->send_counts[p] > 0);
+        *n_neighbours = k;
+    }
+    return BIS_OK;
+}
+
+bis_status bis_dist_profile_read(bis_ctx *ctx, bis_dist *d, int64_t *n_exchange, double *exchange_ms,
+                                 int64_t *n_allreduce, double *allreduce_ms) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d, "bis_dist_profile_read: null handle");
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(d->comm_stream));
+    auto total = [](bis_dist::EvPool &p, int64_t *n, double *ms) {
+        double t = 0.0;
+        for (size_t i = 0; i < p.used; ++i) { float f = 0.f; if (hipEventElapsedTime(&f, p.ev[i].first, p.ev[i].second) == hipSuccess) t += f; }
+        if (n) *n = (int64_t)p.used;
+        if (ms) *ms = t;
+        p.used = 0;
+    };
+    total(d->prof_exchange, n_exchange, exchange_ms);
+    total(d->prof_allreduce, n_allreduce, allreduce_ms);
     return BIS_OK;
 }
 
@@ -379,11 +633,14 @@ bis_status bis_dist_spmv_launch(bis_ctx *ctx, bis_dist *d, double *x_ext, double
         }
         BIS_HIP_CHECK(ctx, hipEventRecord(d->ev_packed, ctx->stream));
         BIS_HIP_CHECK(ctx, hipStreamWaitEvent(d->comm_stream, d->ev_packed, 0));
+        std::pair<hipEvent_t, hipEvent_t> *pe = ctx->profile ? &d->prof_exchange.next() : nullptr;
+        if (pe) hipEventRecord(pe->first, d->comm_stream);
         if (d->ops.exchange(d->ops.user, (void *)d->comm_stream, d->sendbuf, d->send_counts.data(),
                             x_ext + d->n_local, d->recv_counts.data(), d->n_ranks) != 0) {
             ctx->err = "halo exchange failed";
             return BIS_ERR_COMM;
         }
+        if (pe) hipEventRecord(pe->second, d->comm_stream);
         BIS_HIP_CHECK(ctx, hipEventRecord(d->ev_halo, d->comm_stream));
     }
     // interior rows: no remote column, runs under the exchange
@@ -408,10 +665,13 @@ const bis_mat *bis_dist_matrix(const bis_dist *d) { return d->A; }
 bis_status bis_dist_allreduce(bis_ctx *ctx, bis_dist *d, double *buf_dev, int count) {
     if (d->n_ranks == 1) return BIS_OK;
     BIS_REQUIRE(ctx, d->have_ops, "bis_dist: no transport set");
+    std::pair<hipEvent_t, hipEvent_t> *pe = ctx->profile ? &d->prof_allreduce.next() : nullptr;
+    if (pe) hipEventRecord(pe->first, ctx->stream);
     if (d->ops.allreduce_sum(d->ops.user, (void *)ctx->stream, buf_dev, count) != 0) {
         ctx->err = "all-reduce failed";
         return BIS_ERR_COMM;
     }
+    if (pe) hipEventRecord(pe->second, ctx->stream);
     return BIS_OK;
 }
 

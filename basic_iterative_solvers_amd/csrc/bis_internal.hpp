@@ -39,6 +39,9 @@ struct bis_ctx {
     double *scalars_dev = nullptr; // [64]
     double *scalars_host = nullptr; // pinned [64]
     unsigned *counters = nullptr; // [64] tickets / arrival counters (zeroed)
+    // device-side waits that gave up (a lost hand-off in a triangular sweep) set this word (pinned host
+    // memory mapped into the device); every blocking entry point checks it after its synchronisation
+    unsigned *fault_host = nullptr, *fault_dev = nullptr;
 
     std::map<std::string, bis_named_kernel> kernels; // named-kernel registry (SMAX protocol)
 
@@ -53,6 +56,8 @@ struct bis_ctx {
 };
 
 // Tuning knobs (bis_set_option / BIS_* environment variables at first use).
+struct bis_options;
+bis_options &bis_opts();
 struct bis_options {
     int spmv_variant = -1; // -1: default (40 = 256 threads, 4 staged vectors)
     int spmv_window = -1;  // -1: default (0: CRS gather kernel)
@@ -71,8 +76,12 @@ struct bis_options {
     int spmv_packed32 = -1; // 1: also try the 32-window packed format (opt-in)
     int spmv_lds_pad = -1; // diagnostic: extra dynamic LDS bytes per workgroup (lowers occupancy)
     int spmv_packed = -1;  // 16-bit packed column stream: 0 off, 1 select tree, 2 lane permute (-1: default = 1)
+    int dist_host_plan = -1; // 1: bis_dist_create plans the halo on the host from the downloaded structure (default: on the device)
+    int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
+    int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes
 };
-bis_options &bis_opts();
+// row_ptr width of a new matrix: int64 when the non-zeros (plus the stream padding) do not fit int32
+inline bool bis_want_rp64(int64_t nnz) { return nnz >= (int64_t)INT32_MAX - 8 || bis_opts().force_rp64 > 0; }
 
 constexpr int kMaxReduceBlocks = 2048;
 constexpr int kWinMaxTiles = 128; // x window: at most 128 tiles of 16 columns (16 KiB of LDS)
@@ -129,6 +138,14 @@ struct bis_mat {
             (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);    \
             return BIS_ERR_HIP;                                                \
         }                                                                      \
+    } while (0)
+
+// after a stream synchronisation: did a kernel raise the fault word?
+bis_status bis_fault_check(bis_ctx *ctx);
+#define BIS_SYNC_CHECK(ctx)                                                    \
+    do {                                                                       \
+        BIS_HIP_CHECK(ctx, hipStreamSynchronize((ctx)->stream));               \
+        if (bis_status fs_ = bis_fault_check(ctx)) return fs_;                 \
     } while (0)
 
 #define BIS_REQUIRE(ctx, cond, msg)                                            \

@@ -457,7 +457,7 @@ static bis_status mat_create_common(bis_ctx *ctx, int64_t n_rows, int64_t n_cols
                 "bis_mat_create: bad arguments");
     BIS_REQUIRE(ctx, n_rows < INT32_MAX && n_cols < INT32_MAX,
                 "bis_mat_create: row/column count must fit int32 (col is int32)");
-    const bool rp64 = nnz >= (int64_t)INT32_MAX - kPad;
+    const bool rp64 = bis_want_rp64(nnz);
     bis_mat *A = nullptr;
     bis_status st = bis_mat_alloc(ctx, n_rows, n_cols, nnz, rp64, &A);
     if (st != BIS_OK) return st;
@@ -616,6 +616,8 @@ BIS_API bis_status bis_mat_debug_ptrs(const bis_mat *A, void **row_ptr, void **c
     return BIS_OK;
 }
 
+int bis_mat_rp_width(const bis_mat *A) { return A ? (A->rp64 ? 8 : 4) : 0; }
+
 bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz) {
     if (!A) return BIS_ERR_INVALID;
     if (n_rows) *n_rows = A->n_rows;
@@ -659,7 +661,7 @@ bis_status bis_mat_gen_hpcg(bis_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, in
     const int64_t base = hpcg_row_ptr_host(row0, nx, ny, nz);
     const int64_t nnz = hpcg_row_ptr_host(row1, nx, ny, nz) - base;
     const int64_t n_local = row1 - row0;
-    const bool rp64 = nnz >= (int64_t)INT32_MAX - kPad;
+    const bool rp64 = bis_want_rp64(nnz);
     bis_mat *A = nullptr;
     bis_status st = bis_mat_alloc(ctx, n_local, N, nnz, rp64, &A);
     if (st != BIS_OK) return st;
@@ -684,7 +686,7 @@ bis_status bis_mat_gen_anderson(bis_ctx *ctx, int64_t L, double t, double W, dou
     BIS_REQUIRE(ctx, out && L >= 3 && N < INT32_MAX && row0 >= 0 && row0 <= row1 && row1 <= N,
                 "bis_mat_gen_anderson: bad arguments (L >= 3)");
     const int64_t n_local = row1 - row0, nnz = 7 * n_local;
-    const bool rp64 = nnz >= (int64_t)INT32_MAX - kPad;
+    const bool rp64 = bis_want_rp64(nnz);
     bis_mat *A = nullptr;
     bis_status st = bis_mat_alloc(ctx, n_local, N, nnz, rp64, &A);
     if (st != BIS_OK) return st;
@@ -725,7 +727,7 @@ bis_status bis_mat_gen_fem(bis_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { hipFree(blk); ctx->err = "bis_mat_gen_fem: count pass failed"; return BIS_ERR_HIP; }
     const int64_t nnz = h_tot[0];
-    const bool rp64 = nnz >= (int64_t)INT32_MAX - kPad;
+    const bool rp64 = bis_want_rp64(nnz);
     bis_mat *A = nullptr;
     bis_status st = bis_mat_alloc(ctx, n_local, N, nnz, rp64, &A);
     if (st != BIS_OK) { hipFree(blk); return st; }
@@ -791,7 +793,7 @@ bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L
     BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     bis_mat *Lm = nullptr, *Um = nullptr;
     // strict parts of a matrix whose nnz fits int32 also fit
-    const bool rpo64 = A->rp64 && (h_tot[0] >= INT32_MAX - kPad || h_tot[1] >= INT32_MAX - kPad);
+    const bool rpo64 = A->rp64 && (bis_want_rp64(h_tot[0]) || bis_want_rp64(h_tot[1]));
     bis_status st = bis_mat_alloc(ctx, n, n, h_tot[0], rpo64, &Lm);
     if (st == BIS_OK) st = bis_mat_alloc(ctx, n, n, h_tot[1], rpo64, &Um);
     if (st != BIS_OK) { hipFree(blk); if (Lm) bis_mat_destroy(ctx, Lm); return st; }

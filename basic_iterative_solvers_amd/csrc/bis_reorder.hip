@@ -260,6 +260,12 @@ __global__ __launch_bounds__(256) void gather_vec_kernel(const double *__restric
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[perm[i]];
 }
 
+__global__ __launch_bounds__(256) void scatter_vec_kernel(const double *__restrict__ in, const int32_t *__restrict__ perm,
+                                                          int64_t n, double *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[perm[i]] = in[i];
+}
+
 // -scale on the device: extract_scale (utilities/LU_factors.hpp:880-898) + scale_mat
 // (preprocessing.hpp:15-24).  s_r = 1/sqrt(|a_rr|) (the last diagonal entry of the row wins,
 // rows without one keep the caller's value), then a_rc *= (s_r * s_c).
@@ -395,6 +401,16 @@ bis_status bis_vec_gather(bis_ctx *ctx, double *out, const double *in, const int
     BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (out && in && perm_dev)) && out != in, "bis_vec_gather: bad arguments");
     if (n == 0) return BIS_OK;
     hipLaunchKernelGGL(gather_vec_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0,
+                       ctx->stream, in, perm_dev, n, out);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+
+bis_status bis_vec_scatter(bis_ctx *ctx, double *out, const double *in, const int32_t *perm_dev, int64_t n) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (out && in && perm_dev)) && out != in, "bis_vec_scatter: bad arguments");
+    if (n == 0) return BIS_OK;
+    hipLaunchKernelGGL(scatter_vec_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0,
                        ctx->stream, in, perm_dev, n, out);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;

@@ -72,6 +72,7 @@ constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + p
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
 constexpr int kTrsvT = 256;
 constexpr unsigned kSpinLimit = 1u << 22; // polls of one row before it gives up and publishes NaN (seconds)
+constexpr int kWaveBlocksPerCU = 4;       // wave-per-row kernel: resident workgroups per CU the launch bound guarantees
 
 __global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned long long *xs, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
     const RP *__restrict__ row_ptr, const int32_t *__restrict__ dep /* col, or positions (pcol) */,
     const double *__restrict__ val, const int32_t *__restrict__ perm, int64_t n,
     const double *__restrict__ D, const double *b, double *x, unsigned long long *xs,
-    unsigned *ticket, int by_pos) {
+    unsigned *ticket, int by_pos, unsigned *fault) {
     __shared__ unsigned s_ticket;
     if (ONE_XCD) {
         if (threadIdx.x == 0) {
@@ -180,8 +181,10 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
                     }
                 }
                 if (ready < in_batch) { // still pending
-                    if (++spins > kSpinLimit) publish = true; // bounded: a lost hand-off must not hang the GPU (publishes NaN)
-                    else __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kSpinLimit) { // bounded: a lost hand-off must not hang the GPU -- publishes NaN and
+                        publish = true;         // raises the context's fault word (the next blocking call fails)
+                        __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else __builtin_amdgcn_s_sleep(1);
                 }
                 {
                     // The publishing store is predicated INSIDE one volatile asm, with no branch
@@ -220,10 +223,10 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
 // row each) in level order; lanes of a wave never wait for each other, so the
 // wait loop is an ordinary loop here.
 template <typename RP>
-__global__ __launch_bounds__(kTrsvT) void sptrsv_wave_kernel(
+__global__ __launch_bounds__(kTrsvT, kWaveBlocksPerCU) void sptrsv_wave_kernel(
     const RP *__restrict__ row_ptr, const int32_t *__restrict__ dep, const double *__restrict__ val,
     const int32_t *__restrict__ perm, int64_t n, const double *__restrict__ D, const double *b, double *x,
-    unsigned long long *xs, unsigned *ticket, int by_pos) {
+    unsigned long long *xs, unsigned *ticket, int by_pos, unsigned *fault) {
     const int lane = threadIdx.x & 63;
     // Static round robin over the level-sorted positions, no ticket counter (one atomic
     // per row on one address caps the sweep at ~88 M rows/s: 11.4 ns per row measured).
@@ -269,7 +272,11 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_wave_kernel(
                 }
                 folded = upto;
                 if (!pend) break;
-                if (++spins > kSpinLimit) { lost = true; break; } // bounded: publishes NaN below
+                if (++spins > kSpinLimit) { // bounded: publishes NaN below and raises the context's fault word
+                    lost = true;
+                    if (lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
                 if (active && v == kSentinel) v = __hip_atomic_load(&xs[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -392,7 +399,7 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
     bis_trsv_plan *p = new bis_trsv_plan;
     p->n = n;
     hipError_t e = hipMalloc(&p->perm, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1));
-    if (e == hipSuccess) e = hipMalloc(&p->xs, sizeof(double) * (size_t)std::max<int64_t>(n, 1));
+    if (e == hipSuccess) e = hipMalloc(&p->xs, sizeof(double) * (size_t)(n + 1)); // + one slot nobody publishes (test hook)
     if (e == hipSuccess) e = hipMalloc(&p->ticket, sizeof(unsigned) * 4);
     if (e != hipSuccess) {
         ctx->err = std::string("sptrsv plan: ") + hipGetErrorString(e);
@@ -515,7 +522,7 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     }
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,
-                       (unsigned long long *)p->xs, n);
+                       (unsigned long long *)p->xs, n + 1);
     static const unsigned tk[2] = {0u, 0xffffffffu}; // ticket counter, elected XCD (none yet)
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(p->ticket, tk, sizeof tk, hipMemcpyHostToDevice, ctx->stream));
     // persistent grid: resident by construction (<= 8 workgroups of 256 per CU, 51 VGPRs)
@@ -561,6 +568,19 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     }
     const int32_t *dep = (by_pos && p->pcol) ? p->pcol : T->col;
     const int pos_flag = (by_pos && p->pcol) ? 1 : 0;
+    // Test hook (bis_set_option("trsv_inject_loss", k)): the first dependency of the k-th non-zero's row is
+    // redirected, for this one sweep, to the scratch slot nobody publishes -- the row gives up after
+    // kSpinLimit polls, publishes NaN and raises the fault word.
+    struct Restore { bis_ctx *c; int32_t *at; int32_t old; ~Restore() { if (at) { hipMemcpyAsync(at, &old, 4, hipMemcpyHostToDevice, c->stream); hipStreamSynchronize(c->stream); } } } restore{ctx, nullptr, 0};
+    if (bis_opts().trsv_inject_loss > 0 && pos_flag && (int64_t)bis_opts().trsv_inject_loss <= T->nnz) {
+        int32_t *at = p->pcol + (bis_opts().trsv_inject_loss - 1);
+        const int32_t lost = (int32_t)n;
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(&restore.old, at, 4, hipMemcpyDeviceToHost, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(at, &lost, 4, hipMemcpyHostToDevice, ctx->stream));
+        restore.at = at;
+        bis_opts().trsv_inject_loss = -1; // one shot
+    }
     // rows of more than 8 dependencies: one wave per row (config-5 stand-in, ~35 per row: 10.8 / 25.3 ms per
     // forward / backward sweep with a lane per row -> 6.0 / 6.0 ms; HPCG-128, 13 per row: 2.88 / 3.05 -> 2.64 / 2.66;
     // Anderson-256, 3 per row and 22 K rows per level: 2.4 ms with a lane per row, 8.6 ms with a wave per row)
@@ -572,24 +592,38 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     if (wave_mode && !one_xcd) {
         // a few levels of rows in flight, one row per wave; at most 4 workgroups per CU: every wave of the
         // grid must be resident (static round robin, see the kernel)
+        // Rows are dealt to the waves round robin, so EVERY wave of the grid must be resident: the grid is
+        // capped by the occupancy the runtime reports for this kernel (the launch bound guarantees
+        // kWaveBlocksPerCU), whatever trsv_grid asks for.  If the device is shared and some workgroup still
+        // cannot start, its rows are never published: the waiting rows give up after kSpinLimit polls and
+        // the sweep fails with BIS_ERR_SYNC at the next blocking call instead of returning NaNs silently.
+        static int resident[2] = {0, 0};
+        int &res = resident[T->rp64 ? 1 : 0];
+        if (res == 0) {
+            int nb = 0;
+            hipError_t oe = T->rp64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sptrsv_wave_kernel<int64_t>, kTrsvT, 0)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sptrsv_wave_kernel<int32_t>, kTrsvT, 0);
+            res = (oe == hipSuccess && nb > 0) ? std::min(nb, kWaveBlocksPerCU) : 1;
+            (void)hipGetLastError();
+        }
         int64_t wg = (4 * p->max_level_width + 3) / 4 + 1;
         if (bis_opts().trsv_grid > 0) wg = bis_opts().trsv_grid;
-        wg = std::max<int64_t>(1, std::min<int64_t>(wg, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->n_cus * 4)));
+        wg = std::max<int64_t>(1, std::min<int64_t>(wg, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->n_cus * res)));
         if (T->rp64)
             hipLaunchKernelGGL(sptrsv_wave_kernel<int64_t>, dim3((unsigned)wg), dim3(kTrsvT), 0, ctx->stream,
                                (const int64_t *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,
-                               (unsigned long long *)p->xs, p->ticket, pos_flag);
+                               (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev);
         else
             hipLaunchKernelGGL(sptrsv_wave_kernel<int32_t>, dim3((unsigned)wg), dim3(kTrsvT), 0, ctx->stream,
                                (const int32_t *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,
-                               (unsigned long long *)p->xs, p->ticket, pos_flag);
+                               (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev);
         BIS_HIP_CHECK(ctx, hipGetLastError());
         return BIS_OK;
     }
 #define BIS_TRSV_LAUNCH(RP, ONE, B)                                                                    \
     hipLaunchKernelGGL((sptrsv_syncfree_kernel<RP, ONE, B>), dim3(grid), dim3(kTrsvT), 0, ctx->stream, \
                        (const RP *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,                      \
-                       (unsigned long long *)p->xs, p->ticket, pos_flag)
+                       (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev)
 #define BIS_TRSV_B(RP, ONE)                                                                            \
     do {                                                                                               \
         if (batch >= 32) BIS_TRSV_LAUNCH(RP, ONE, 32);                                                 \

@@ -1,5 +1,8 @@
-"""bench.py, N > 1: strong scaling of the fused CG on the row-partitioned HPCG
-operator (z-slabs), one process per GPU, RCCL over xGMI."""
+"""bench.py, N > 1: strong scaling of the fused CG on the row-partitioned operator
+(z-slabs), one process per GPU, RCCL over xGMI.  --matrix hpcg is the BASELINE metric
+(HPCG 256^3, -cg); --matrix anderson --precond j is BASELINE config 3 (Anderson 256^3,
+Jacobi-preconditioned CG, row-partitioned): shift 0 is the config as named (indefinite: a
+timing workload), shift 9 its conditioned twin with the r0 check."""
 import json
 import os
 import time
@@ -7,6 +10,33 @@ import time
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0
+
+
+def anderson_diag(L, W, shift, seed, row0, row1):
+    """Diagonal of the Anderson generator (bis_mat_gen_anderson / oracle orc_gen_anderson): the same
+    counter hash in numpy uint64 arithmetic -- the partition-independent side of the r0 check."""
+    i = np.arange(row0, row1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + (i + np.uint64(1)) * np.uint64(0xD1B54A32D192ED03)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return W * (u - 0.5) + shift
+
+
+def r0_closed_form(args, n1):
+    """||b - A x0||_2 for b = 1, x0 = 0.1 from the row sums alone (independent of the partition)."""
+    if args.matrix == "hpcg":  # row sum 27 - cx*cy*cz
+        c = np.full(n1, 3.0); c[0] = c[-1] = 2.0
+        rowsum = 27.0 - c[:, None, None] * c[None, :, None] * c[None, None, :]
+        return float(np.sqrt(np.sum((1.0 - 0.1 * rowsum) ** 2)))
+    # Anderson: diagonal + 6 off-diagonals of -t (t = 1); summed in chunks of 2^22 rows
+    tot, N = 0.0, n1 ** 3
+    for a in range(0, N, 1 << 22):
+        d = anderson_diag(n1, 5.0, args.shift, 1, a, min(N, a + (1 << 22)))
+        tot += float(np.sum((1.0 - 0.1 * (d - 6.0)) ** 2))
+    return float(np.sqrt(tot))
 
 
 def run_distributed(args, rank, world, local_rank):
@@ -37,9 +67,18 @@ def run_distributed(args, rank, world, local_rank):
     row0, row1 = int(row_starts[rank]), int(row_starts[rank + 1])
     if getattr(args, "tune_placement", 0) > 0:  # applied inside bis_dist_create, before the row views
         ctx.lib.bis_set_option(b"tune_placement", int(args.tune_placement))
-    A = ctx.gen_hpcg(n1, row0=row0, row1=row1)
+    t_setup = time.perf_counter()
+    if args.matrix == "hpcg":
+        A = ctx.gen_hpcg(n1, row0=row0, row1=row1)
+    else:
+        A = ctx.gen_anderson(n1, shift=args.shift, row0=row0, row1=row1)
     nnz_local = A.nnz
+    D = None
+    if args.precond == "j":  # the Jacobi diagonal of this rank's rows, taken before the columns are renumbered
+        D, Dinv = ctx.mat_diag(A, row0)
+        Dinv.free()
     d = Dist(ctx, A, rank, world, row_starts)
+    setup_s = time.perf_counter() - t_setup
     route_send_lists(d, td, group=host_group)
     transport = "rccl (native ncclSend/ncclRecv + ncclAllReduce on the library's streams)"
     try:
@@ -59,17 +98,11 @@ def run_distributed(args, rank, world, local_rank):
     b, x = ctx.alloc(nl), ctx.alloc(nl)
     ctx.init_vector(b, 1.0)
     ctx.init_vector(x, 0.1)
-    D = None
-    if args.precond == "j":
-        D = ctx.alloc(nl)
-        ctx.init_vector(D, 26.0)
     cg = d.cg(b, x, D)
     r0 = cg.init(0.0)
-    # partition-independent check of the distributed operator: ||b - A x0||_2 in closed form
-    # (row sums of the HPCG operator: 27 - cx*cy*cz neighbours), x0 = 0.1, b = 1
-    c = np.full(n1, 3.0); c[0] = c[-1] = 2.0
-    rowsum = 27.0 - c[:, None, None] * c[None, :, None] * c[None, None, :]
-    r0_exact = float(np.sqrt(np.sum((1.0 - 0.1 * rowsum) ** 2)))
+    # partition-independent check of the distributed operator: ||b - A x0||_2 from the row sums
+    # (x0 = 0.1, b = 1); every rank evaluates the same closed form
+    r0_exact = r0_closed_form(args, n1)
     if not abs(r0 - r0_exact) <= 1e-10 * r0_exact:
         raise SystemExit(f"rank {rank}: distributed residual {r0!r} != {r0_exact!r}: partitioned operator is wrong")
     cg.iterate(args.warmup)
@@ -87,7 +120,15 @@ def run_distributed(args, rank, world, local_rank):
     t1 = time.perf_counter()
     ctx.profile(False)
     launches, spmv_ms = ctx.profile_read()
+    comm = d.profile_read()
     iters, conv, hist = cg.status(hist_cap=args.warmup + args.steps + 1)
+    mine = dict(rank=rank, device=local_rank, rows=nl, nnz=nnz_local, setup_s=setup_s, **d.stats(),
+                spmv_ms_per_iter=spmv_ms / max(args.steps, 1),
+                exchange_ms_per_iter=comm["exchange_ms"] / max(args.steps, 1),
+                allreduce_ms_per_iter=comm["allreduce_ms"] / max(args.steps, 1),
+                exchanges=comm["exchanges"], allreduces=comm["allreduces"])
+    per_rank = [None] * world
+    td.all_gather_object(per_rank, mine, group=host_group)
     el = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     td.all_reduce(el, op=td.ReduceOp.MAX)
     secs = float(el.item())
@@ -104,19 +145,22 @@ def run_distributed(args, rank, world, local_rank):
         spmv_avg_s = float(mx[1].item()) * 1e-3 / args.steps
         spmv_bytes = 12 * nnz + 20 * N
         achieved = spmv_bytes / spmv_avg_s / 1e9
+        name = f"HPCG {n1}^3 27-point" if args.matrix == "hpcg" else \
+            f"Anderson {n1}^3 7-point periodic W=5 shift={args.shift:g}"
         out = {
             "metric": "CG iterations/sec + SpMV GFLOP/s (% HBM roofline), HPCG 256^3 at 1/2/4/8 GPUs",
             "value": its, "unit": "CG iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"HPCG {n1}^3 27-point, -cg" +
+            "config": {"workload": f"{name}, -cg" +
                                    (" -p j" if args.precond == "j" else "") +
                                    ", b=1 x0=0.1, fused device schedule", "rows": N, "nnz": nnz,
                        "partition": f"1-D row blocks (z-slabs) over {world} GPUs, RCCL send/recv halo + "
                                     "2 all-reduces per iteration"},
             "spmv_gflops": 2.0 * nnz / spmv_avg_s / 1e9,
-            "residual_r0": r0, "residual_last": float(hist[-1]), "transport": transport,
+            "residual_r0": r0, "residual_r0_closed_form": r0_exact, "residual_last": float(hist[-1]),
+            "transport": transport, "per_rank": per_rank,
             "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (interior + boundary launches)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,

@@ -78,6 +78,7 @@ struct Args {
     bool unfused = false; // -unfused: CG runs the reference's kernel-by-kernel schedule
     std::string perm_mode = "none"; // -perm mc: multi-colour reordering (SMAX PERM_MODE role)
     std::string dump_perm;          // -dump-perm FILE: write perm[new]=old
+    std::string dump_x;             // -dump-x FILE: write x* (natural row order, also after -perm)
     std::string crs_cache;          // -cache FILE: binary CRS next to a .mtx input (read if present, else written)
     bool perm_host = false;         // -perm-host: colour and permute on the host (fallback path)
     int device = 0;

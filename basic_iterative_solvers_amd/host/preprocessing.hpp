@@ -129,7 +129,8 @@ inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::u
                 to_device(solver->b, pb.data(), N);
             }
         }
-        bis::check(bis_vec_free(bis::ctx(), perm_store), "bis_vec_free");
+        if (mc == BIS_OK) solver->perm_store = perm_store; // kept: x* goes back to the natural order after the solve
+        else { bis::check(bis_vec_free(bis::ctx(), perm_store), "bis_vec_free"); solver->keep_permutation(perm); }
         if (!cli_args->dump_perm.empty()) write_permutation(cli_args->dump_perm, perm);
         std::cout << "multi-colour reordering: " << n_colours << " colours" << std::endl;
     } else if (cli_args->perm_mode == "rcm" || cli_args->perm_mode == "bfs") {
@@ -149,6 +150,7 @@ inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::u
             for (int i = 0; i < N; ++i) pb[i] = hb[perm[i]];
             to_device(solver->b, pb.data(), N);
         }
+        solver->keep_permutation(perm);
         if (!cli_args->dump_perm.empty()) write_permutation(cli_args->dump_perm, perm);
         std::cout << (cli_args->perm_mode == "rcm" ? "reverse Cuthill-McKee" : "breadth-first") << " reordering" << std::endl;
     } else if (cli_args->perm_mode != "none") {

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <cfloat>
+#include <cstring>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -36,6 +37,21 @@ class Solver {
     double *time_per_iteration = nullptr;       // host
     bool convergence_flag = false;
     bool gmres_restarted = false;
+    // -perm: perm[new] = old as int32 in device storage (nullptr: natural order).  The solve runs on
+    // P A P^T; unpermute_x_star() returns x* in the caller's row order.
+    double *perm_store = nullptr;
+    void keep_permutation(const std::vector<int> &perm) {
+        const long n = (long)perm.size();
+        std::vector<double> raw((n + 1) / 2 + 1, 0.0);
+        std::memcpy(raw.data(), perm.data(), sizeof(int) * (size_t)n);
+        if (!perm_store) perm_store = dalloc((n + 1) / 2 + 1);
+        to_device(perm_store, raw.data(), (n + 1) / 2 + 1);
+    }
+    void unpermute_x_star() {
+        if (!perm_store) return;
+        bis::check(bis_vec_scatter(bis::ctx(), tmp, x_star, reinterpret_cast<const int32_t *>(perm_store), N), "bis_vec_scatter");
+        copy_vector(x_star, tmp, N);
+    }
 
     explicit Solver(const Args *a)
         : method(a->method), preconditioner(a->preconditioner), gmres_restart_len(a->restart_length),
@@ -74,6 +90,7 @@ class Solver {
     virtual ~Solver() {
         double *v[] = {x_star, x_0, b, tmp, work, residual, residual_0, A_D, A_D_inv, A_D_scale, L_D, U_D};
         for (auto p : v) dfree(p);
+        dfree(perm_store);
         delete[] collected_residual_norms;
         delete[] time_per_iteration;
     }

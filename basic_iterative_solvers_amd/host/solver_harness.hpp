@@ -31,4 +31,15 @@ inline void solve(Args *cli_args, Solver *solver, Timers *timers) {
     } while (!solver->check_stopping_criteria());
     if (solver->residual_norm < solver->stopping_criteria) solver->convergence_flag = true;
     TIME(timers, "save_x_star", solver->save_x_star())
+    // -perm: the solve ran on P A P^T; hand x* back in the caller's row order (the reference's SMAX path
+    // leaves it permuted, smax_helpers.hpp:44-80)
+    solver->unpermute_x_star();
+    if (!cli_args->dump_x.empty()) { // -dump-x FILE: x* as text, one %.17g value per line (tests)
+        std::vector<double> xs(solver->N);
+        to_host(xs.data(), solver->x_star, solver->N);
+        FILE *f = fopen(cli_args->dump_x.c_str(), "w");
+        if (!f) { fprintf(stderr, "ERROR: cannot write %s\n", cli_args->dump_x.c_str()); exit(EXIT_FAILURE); }
+        for (double v : xs) fprintf(f, "%.17g\n", v);
+        fclose(f);
+    }
 }

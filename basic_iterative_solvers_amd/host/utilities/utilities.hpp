@@ -60,6 +60,7 @@ inline void parse_cli(Args *a, int argc, char *argv[]) {
         else if (arg == "-unfused") a->unfused = true;
         else if (arg == "-perm" && i + 1 < argc) a->perm_mode = argv[++i];
         else if (arg == "-dump-perm" && i + 1 < argc) a->dump_perm = argv[++i];
+        else if (arg == "-dump-x" && i + 1 < argc) a->dump_x = argv[++i];
         else if (arg == "-perm-host") a->perm_host = true;
         else if (arg == "-cache" && i + 1 < argc) a->crs_cache = argv[++i];
         else if (arg == "-dev" && i + 1 < argc) a->device = atoi(argv[++i]);

@@ -40,10 +40,31 @@ def route_send_lists(dist_op, td, group=None):
     return send_counts
 
 
+def negotiate_rccl_id(td, rank, n_ranks, make_id, group=None):
+    """Collective decision whether the native RCCL transport can be used.  EVERY rank calls
+    `make_id` (bis_rccl_unique_id: loads and binds librccl, ncclGetUniqueId) and the outcomes are
+    all-gathered over the host-side group, so all ranks reach the same answer at the same point:
+    (rank 0's id, None) if every rank could bind RCCL, else (None, reason).  A failure on one
+    rank -- rank 0 included -- can therefore never leave the others waiting in a broadcast."""
+    try:
+        mine, err = make_id(), None
+    except Exception as ex:  # BisError, OSError ... anything: report it, do not desert the collective
+        mine, err = None, f"rank {rank}: {ex}"
+    gathered = [None] * n_ranks
+    td.all_gather_object(gathered, (mine, err), group=group)
+    errors = [e for (_, e) in gathered if e]
+    if errors or gathered[0][0] is None:
+        return None, "; ".join(errors) or "rank 0 produced no id"
+    return gathered[0][0], None
+
+
 def setup_rccl(ctx, dist_op, td, group=None):
-    obj = [rccl_unique_id(ctx) if dist_op.rank == 0 else None]
-    td.broadcast_object_list(obj, src=0, group=group)
-    dist_op.use_rccl(obj[0])
+    """Native RCCL transport on every rank, or BisError on every rank (collective, see above)."""
+    from . import BisError
+    uid, why = negotiate_rccl_id(td, dist_op.rank, dist_op.n_ranks, lambda: rccl_unique_id(ctx), group)
+    if uid is None:
+        raise BisError(f"native RCCL transport unavailable: {why}")
+    dist_op.use_rccl(uid)
 
 
 class _DevArray:

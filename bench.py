@@ -34,7 +34,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=256, help="HPCG grid edge (256 = metric size)")
     ap.add_argument("--precond", default="none", choices=["none", "j"])
+    ap.add_argument("--matrix", default="hpcg", choices=["hpcg", "anderson"],
+                    help="hpcg: the BASELINE metric; anderson (+ --precond j): BASELINE configs 2/3")
+    ap.add_argument("--shift", type=float, default=0.0,
+                    help="Anderson diagonal shift: 0 = the config as named (indefinite, timing only), "
+                         "9 = the conditioned twin (SPD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-target-512", action="store_true",
+                    help="skip the HPCG-512 sub-record (north-star target size, int64 row pointers)")
     ap.add_argument("--tune-placement", type=int, default=0,
                     help="setup: keep the fastest of K re-allocations of the matrix' streamed arrays "
                          "(bis_mat_tune_placement; 0 = off)")
@@ -42,6 +49,88 @@ def parse():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "spmv_traffic.json"),
                     help="per-launch HBM bytes from the rocprofv3 PMC passes, if collected")
     return ap.parse_args()
+
+
+def host_topology():
+    """Sockets / physical cores / logical CPUs of this box and the CPUs this process may run on."""
+    topo = {"logical_cpus": os.cpu_count()}
+    try:
+        topo["cpus_allowed"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        phys, socks, model = set(), set(), None
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+                socks.add(pid)
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+                phys.add((pid, cid))
+            elif line.startswith("model name") and model is None:
+                model = line.split(":")[1].strip()
+        topo.update(sockets=len(socks) or None, physical_cores=len(phys) or None, cpu_model=model)
+    except Exception:
+        pass
+    return topo
+
+
+def measured_stream(ctx, N):
+    """Streaming ceiling of THIS box: the library's own axpy-class kernel (sum_vectors, 24 B per
+    element: two reads, one write) and copy (16 B) over N-vectors, wall-clocked over 100 queued launches."""
+    a, b, c = ctx.alloc(N), ctx.alloc(N), ctx.alloc(N)
+    ctx.init_vector(a, 1.0); ctx.init_vector(b, 2.0)
+    out = {}
+    for name, fn, nbytes in (("triad", lambda: ctx.sum_vectors(c, a, b, 0.5), 24 * N),
+                             ("copy", lambda: ctx.copy_vector(c, a), 16 * N)):
+        for _ in range(5):
+            fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            fn()
+        ctx.sync()
+        out[name] = 100 * nbytes / (time.perf_counter() - t0) / 1e9
+    for v in (a, b, c):
+        v.free()
+    return out
+
+
+def target_512(ctx, steps=10, warmup=3):
+    """North-star target size: CG on HPCG 512^3 (3.6e9 nnz, int64 row pointers), same fused schedule;
+    the reference's int CRS cannot hold this matrix, so there is no CPU leg (tests/test_gpu_kernels.py
+    gates it through closed forms and the fused-vs-unfused history)."""
+    n1 = 512
+    N = n1 ** 3
+    A = ctx.gen_hpcg(n1)
+    b, x = ctx.alloc(N), ctx.alloc(N)
+    ctx.init_vector(b, 1.0)
+    ctx.init_vector(x, 0.1)
+    cg = ctx.cg(A, b, x)
+    r0 = cg.init(0.0)
+    cg.iterate(warmup)
+    ctx.sync()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    cg.iterate(steps)
+    ctx.sync()
+    secs = time.perf_counter() - t0
+    ctx.profile(False)
+    launches, spmv_ms = ctx.profile_read()
+    iters, conv, hist = cg.status(hist_cap=warmup + steps + 1)
+    assert iters == warmup + steps
+    spmv_bytes = 12 * A.nnz + 24 * N  # + 4 N for the int64 row pointers
+    avg_s = spmv_ms * 1e-3 / max(launches, 1)
+    rec = {"workload": "HPCG 512^3 27-point, -cg, b=1 x0=0.1, fused device schedule, int64 row_ptr",
+           "rows": N, "nnz": A.nnz, "rp_width": A.rp_width, "steps": steps, "warmup": warmup,
+           "cg_iterations_per_s": steps / secs, "ms_per_step": 1e3 * secs / steps,
+           "spmv_avg_launch_ms": avg_s * 1e3, "spmv_launches": launches,
+           "spmv_algorithmic_bytes": spmv_bytes, "spmv_GBs": spmv_bytes / avg_s / 1e9,
+           "spmv_frac_of_peak": spmv_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+           "spmv_gflops": 2.0 * A.nnz / avg_s / 1e9, "residual_r0": r0, "residual_last": float(hist[-1])}
+    cg.free(); A.free(); b.free(); x.free()
+    return rec
 
 
 def cpu_baseline(size, precond, iters):
@@ -71,6 +160,8 @@ def cpu_baseline(size, precond, iters):
         secs = r["iterate_s"] + r["sample_s"]
         n_it = r["iters"]
         return dict(value=n_it / secs, unit="CG iterations/s", cores=threads, kind="reference",
+                    topology=host_topology(), omp_proc_bind=os.environ.get("OMP_PROC_BIND"),
+                    omp_places=os.environ.get("OMP_PLACES"),
                     sample=f"HPCG {size}^3 ({A.nnz} nnz), {n_it} CG iterations of the reference's own "
                            f"ConjugateGradientSolver (oracle/_ref, g++ -O3 -march=native -fopenmp, "
                            f"{threads} OpenMP threads), iterate+sample time from its timer tree; "
@@ -78,6 +169,8 @@ def cpu_baseline(size, precond, iters):
                     ms_per_step=1e3 * secs / n_it), r["hist"]
     hist, secs = orc.cg_run(A, iters, D)
     return dict(value=iters / secs, unit="CG iterations/s", cores=threads, kind="port",
+                topology=host_topology(), omp_proc_bind=os.environ.get("OMP_PROC_BIND"),
+                omp_places=os.environ.get("OMP_PLACES"),
                 sample=f"HPCG {size}^3 ({A.nnz} nnz), {iters} CG iterations of the oracle's OpenMP "
                        f"port (oracle/bis_oracle.c orc_cg_run), {threads} threads, "
                        f"matrix generated on host in {gen_s:.1f} s",
@@ -86,6 +179,9 @@ def cpu_baseline(size, precond, iters):
 
 def main():
     args = parse()
+    # the CPU leg's OpenMP binding, fixed before libgomp starts
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import torch  # plumbing: device sync + torch.distributed launcher contract
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +197,11 @@ def main():
 
     from basic_iterative_solvers_amd import Context
 
-    if world > 1 or os.environ.get("BIS_FORCE_DIST") == "1":
+    if world > 1 or os.environ.get("BIS_FORCE_DIST") == "1" or args.matrix != "hpcg":
+        # the partitioned runner also serves N = 1 (a 1-rank communicator): Anderson configs, and
+        # BIS_FORCE_DIST=1 to compare the distributed code path with the plain one on the same problem
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
         from basic_iterative_solvers_amd.dist_bench import run_distributed
         return run_distributed(args, rank, world, local_rank)
 
@@ -152,6 +252,7 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    stream = measured_stream(ctx, N)
     fused_bytes = 12 * nnz + (108 if args.precond == "j" else 92) * N
     out = {
         "metric": "CG iterations/sec + SpMV GFLOP/s (% HBM roofline), HPCG 256^3 at 1/2/4/8 GPUs",
@@ -169,7 +270,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": spmv_bytes,
-                     "avg_launch_ms": spmv_avg_s * 1e3, "launches": launches},
+                     "avg_launch_ms": spmv_avg_s * 1e3, "launches": launches,
+                     # the streaming ceiling measured on this box: the library's
+                     # own triad over N-vectors; frac_of_measured prices the SpMV against it
+                     "measured_stream_GBs": stream["triad"], "measured_copy_GBs": stream["copy"],
+                     "frac_of_measured": achieved / stream["triad"]},
     }
     if not args.no_cpu_baseline:
         cb, cpu_hist = cpu_baseline(n1, args.precond, args.cpu_iters)
@@ -180,8 +285,12 @@ def main():
         out["parity_max_dr_over_r0"] = float(np.max(np.abs(cpu_hist[:m] - hist[:m])) / cpu_hist[0])
     if tuned:
         out["placement_tuning"] = tuned
+    cg.free(); A.free(); b.free(); x.free()
+    if n1 == 256 and not args.no_target_512:
+        info = ctx.device_info()
+        if info["hbm_bytes"] >= 200e9:
+            out["target_512"] = target_512(ctx)
     print(json.dumps(out), flush=True)
-    cg.free()
     ctx.close()
 
 

@@ -49,7 +49,10 @@ enum {
     BIS_ERR_ZERO_DIAG = 4,   /* SanityChecker::zero_diag, common.hpp:388-391 */
     BIS_ERR_NO_DIAG = 5,     /* SanityChecker::no_diag,   common.hpp:393-396 */
     BIS_ERR_UNSUPPORTED = 6, /* e.g. a row longer than the kernel supports */
-    BIS_ERR_COMM = 7         /* RCCL / halo-exchange failure */
+    BIS_ERR_COMM = 7,        /* RCCL / halo-exchange failure */
+    BIS_ERR_SYNC = 8         /* a device-side wait gave up (lost hand-off in a
+                                triangular sweep): results of the work queued
+                                since the last blocking call are invalid */
 };
 
 /* PrecondType, common.hpp:38-47 (same ordinals). */
@@ -80,7 +83,8 @@ BIS_API void *bis_ctx_stream(bis_ctx *ctx);
 BIS_API bis_status bis_device_info(bis_ctx *ctx, char *arch, size_t arch_len,
                                    int *n_cus, int64_t *hbm_bytes);
 /* Tuning knobs, process-wide: "spmv_variant", "spmv_window", "spmv_chunk",
- * "trsv_grid" (-1 = default).  Matrices created afterwards pick them up. */
+ * "trsv_grid" (-1 = default), "force_rp64" (1: 64-bit row pointers at any
+ * size).  Matrices created afterwards pick them up. */
 BIS_API bis_status bis_set_option(const char *name, int value);
 /* number of exported kernel-level symbols, for the load test */
 BIS_API int bis_abi_version(void);
@@ -112,6 +116,10 @@ BIS_API bis_status bis_mat_create64(bis_ctx *ctx, int64_t n_rows,
 BIS_API bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A);
 BIS_API bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows,
                                 int64_t *n_cols, int64_t *nnz);
+/* bytes per row pointer on the device: 4, or 8 when nnz >= 2^31 (HPCG-512) or
+ * bis_set_option("force_rp64", 1) was in effect when the matrix was made (the
+ * tests run the 64-bit instantiations at small sizes that way). */
+BIS_API int bis_mat_rp_width(const bis_mat *A);
 /* rebuild a matrix' row-block metadata after bis_set_option (tuning) */
 BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
 /* Placement tuning (setup, optional): WHERE in HBM the streamed arrays of a matrix
@@ -186,6 +194,11 @@ BIS_API bis_status bis_mat_multicolour(bis_ctx *ctx, const bis_mat *A,
                                        int *n_colours);
 BIS_API bis_status bis_vec_gather(bis_ctx *ctx, double *out, const double *in,
                                   const int32_t *perm_dev, int64_t n);
+/* out[perm[i]] = in[i]: the inverse permutation without forming it -- returns
+ * x* of a permuted solve in the caller's original row order (the reference's
+ * SMAX path leaves x* permuted, smax_helpers.hpp:44-80).  out != in. */
+BIS_API bis_status bis_vec_scatter(bis_ctx *ctx, double *out, const double *in,
+                                   const int32_t *perm_dev, int64_t n);
 
 /* ILU(0) on the device: the arithmetic of the
  * reference's serial factor_ILU0_old (utilities/LU_factors.hpp:320-539),
@@ -367,6 +380,15 @@ BIS_API bis_status bis_halo_plan(int64_t n_local, const int64_t *row_ptr,
 
 typedef struct bis_dist bis_dist;
 
+/* Diagonal of a row block that still carries GLOBAL column indices (call it
+ * before bis_dist_create renumbers them): D[r] = a(r, row_offset + r), the
+ * last diagonal entry of a row wins (peel_diag_crs, utilities/LU_factors.hpp:
+ * 827-869); D_inv (optional) = 1/D.  BIS_ERR_NO_DIAG / BIS_ERR_ZERO_DIAG with
+ * the reference's SanityChecker texts.  This is what gives every rank the
+ * Jacobi preconditioner of its rows (config 3: -cg -p j across GPUs). */
+BIS_API bis_status bis_mat_diag(bis_ctx *ctx, const bis_mat *A_local,
+                                int64_t row_offset, double *D, double *D_inv);
+
 /* Transport, provided by the launcher or by bis_dist_use_rccl.  Buffers are
  * DEVICE pointers; the operation must be ordered on `stream` (a hipStream_t).
  * Return 0 on success. */
@@ -414,6 +436,19 @@ BIS_API bis_status bis_dist_set_comm(bis_ctx *ctx, bis_dist *d,
 BIS_API bis_status bis_rccl_unique_id(bis_ctx *ctx, void *out128);
 BIS_API bis_status bis_dist_use_rccl(bis_ctx *ctx, bis_dist *d,
                                      const void *unique_id128);
+/* What the partition costs this rank: halo entries received and boundary
+ * entries sent per SpMV (8 bytes each), rows of the interior run that overlaps
+ * the exchange, the number of peers it talks to, and the size of the RCCL
+ * communicator it joined (ncclCommCount; 0 when the transport is not RCCL). */
+BIS_API bis_status bis_dist_stats(const bis_dist *d, int64_t *n_halo,
+                                  int64_t *n_send, int64_t *interior_rows,
+                                  int *n_neighbours, int *rccl_ranks);
+/* While bis_profile_enable is on, every halo exchange (on the communication
+ * stream) and every scalar all-reduce (on the compute stream) is bracketed by
+ * HIP events; returns counts and summed milliseconds and resets (blocking). */
+BIS_API bis_status bis_dist_profile_read(bis_ctx *ctx, bis_dist *d,
+                                         int64_t *n_exchange, double *exchange_ms,
+                                         int64_t *n_allreduce, double *allreduce_ms);
 /* y_local = (A x)_local.  x_ext has n_ext entries (owned part filled by the
  * caller); the halo exchange runs on a second stream under the interior rows'
  * SpMV, the boundary rows follow. */

@@ -5,6 +5,8 @@ torch.distributed.run from test_dist_*.py).  Modes:
                       launcher's routing protocol, with the ORACLE standing in
                       for the device kernels (test infrastructure only), against
                       the single-process oracle.
+  negotiate . .       the collective RCCL-or-fallback decision of the N > 1 bench with
+                      injected per-rank binding failures (no GPU, no RCCL).
   gpu <kind> <size>   gloo transport through the C-ABI communicator callbacks,
                       HIP kernels on cuda:0 (ranks share the one GPU of the
                       box), against the single-process oracle.
@@ -35,6 +37,26 @@ def main():
 
     td.init_process_group("gloo")
     rank, world = td.get_rank(), td.get_world_size()
+    if mode == "negotiate":
+        # the N > 1 bench's transport decision is collective: a rank that cannot bind RCCL (rank 0
+        # included) makes EVERY rank fall back at the same point -- nobody waits in a broadcast
+        from basic_iterative_solvers_amd.launcher import negotiate_rccl_id
+
+        def failing(on):
+            def make():
+                if rank == on:
+                    raise OSError("librccl.so.1: cannot open shared object file")
+                return bytes([rank]) * 128
+            return make
+        for bad in range(world):
+            uid, why = negotiate_rccl_id(td, rank, world, failing(bad))
+            assert uid is None and f"rank {bad}:" in why and "librccl" in why, (uid, why)
+        uid, why = negotiate_rccl_id(td, rank, world, failing(-1))
+        assert why is None and uid == bytes([0]) * 128  # everybody holds rank 0's id
+        print(f"rank {rank}/{world} negotiate OK", flush=True)
+        td.barrier()
+        td.destroy_process_group()
+        return
     orc = Oracle()
     N = size ** 3
     # uneven split on purpose when world == 3; plane-aligned for hpcg
@@ -130,6 +152,15 @@ def main():
         ctx = Context(0)
         dA = ctx.matrix(A_loc)
         d = Dist(ctx, dA, rank, world, row_starts)
+        # the device-side halo plan (only remote entries and boundary rows leave HBM) equals the
+        # host planner on the full structure: same halo columns, same per-owner counts, same interior run
+        h_halo, h_recv, h_int = halo_plan(nl, A_loc.row_ptr, A_loc.col, world, rank, row_starts)
+        d_halo, d_recv = d.halo_info()
+        assert np.array_equal(d_halo, h_halo) and np.array_equal(d_recv, h_recv)
+        assert d.stats()["interior_rows"] == int(h_int[1] - h_int[0])
+        # Jacobi diagonal of the local rows from the device (bis_mat_diag) == the matrix' own
+        dA2 = ctx.matrix(A_loc)
+        dD, dDinv = ctx.mat_diag(dA2, row0)
         route_send_lists(d, td)
         if (world == 1 and kind == "hpcg") or os.environ.get("BIS_TEST_FORCE_RCCL") == "1":
             setup_rccl(ctx, d, td)  # exercises the RCCL binding (self all-reduce)
@@ -149,7 +180,8 @@ def main():
         assert abs(gd - exact) <= 1e-12 * abs(exact) + 1e-12 * N
         Dg = np.array([A_glob.val[A_glob.row_ptr[r]:A_glob.row_ptr[r + 1]][
             A_glob.col[A_glob.row_ptr[r]:A_glob.row_ptr[r + 1]] == r][0] for r in range(row0, row1)])
-        bv, xv, Dv = ctx.upload(np.full(nl, 1.0)), ctx.upload(np.full(nl, 0.1)), ctx.upload(Dg)
+        assert np.array_equal(dD.to_host(), Dg) and np.array_equal(dDinv.to_host(), 1.0 / Dg)
+        bv, xv, Dv = ctx.upload(np.full(nl, 1.0)), ctx.upload(np.full(nl, 0.1)), dD
         cg = d.cg(bv, xv, Dv)
         r0 = cg.init(1e-14)
         cg.iterate(200)

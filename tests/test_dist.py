@@ -35,6 +35,13 @@ def test_partitioned_cg_gloo_cpu(world, kind, size):
     launch(world, "cpu", kind, size)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_negotiation_is_collective(world):
+    """A rank that cannot load / bind RCCL -- rank 0 included -- must not leave the others
+    waiting: every rank learns the outcome in the same all-gather (launcher.negotiate_rccl_id)."""
+    launch(world, "negotiate", "-", 0, timeout=300)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 12), (3, "anderson", 7), (1, "hpcg", 8)])
 def test_partitioned_cg_hip(world, kind, size):
@@ -42,8 +49,8 @@ def test_partitioned_cg_hip(world, kind, size):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,precond", [(2, "none"), (3, "j")])
-def test_bench_multi_gpu_path_rehearsal(world, precond):
+@pytest.mark.parametrize("world,precond,matrix", [(2, "none", "hpcg"), (3, "j", "hpcg"), (2, "j", "anderson"), (3, "j", "anderson0")])
+def test_bench_multi_gpu_path_rehearsal(world, precond, matrix):
     """bench.py --gpus N exactly as the driver launches it (torch.distributed.run, one process
     per rank), on ONE GPU: BIS_BENCH_REHEARSE=1 puts every rank on cuda:0 with the gloo
     transport, so everything of the N > 1 bench except RCCL itself runs -- partition,
@@ -53,6 +60,8 @@ def test_bench_multi_gpu_path_rehearsal(world, precond):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "48", "--steps", "6", "--warmup", "2",
            "--precond", precond]
+    if matrix.startswith("anderson"):  # BASELINE config 3's runner: the conditioned twin and the config as named
+        cmd += ["--matrix", "anderson", "--shift", "9" if matrix == "anderson" else "0"]
     env = dict(os.environ, OMP_NUM_THREADS="1", BIS_BENCH_REHEARSE="1")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
@@ -62,4 +71,11 @@ def test_bench_multi_gpu_path_rehearsal(world, precond):
     assert j["n_gpus"] == world and j["steps"] == 6 and j["warmup"] == 2 and j["scaling"] == "strong"
     assert j["value"] > 0 and j["unit"] == "CG iterations/s" and j["config"]["rows"] == 48 ** 3
     assert j["roofline"]["achieved"] > 0 and j["roofline"]["peak"] == 8000.0 * world
-    assert 0 < j["residual_last"] < j["residual_r0"] * 10
+    if matrix != "anderson0":  # the raw Anderson operator is indefinite: CG need not reduce the residual
+        assert 0 < j["residual_last"] < j["residual_r0"] * 10
+    assert abs(j["residual_r0"] - j["residual_r0_closed_form"]) <= 1e-10 * j["residual_r0"]
+    pr = j["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(world)) and sum(p["rows"] for p in pr) == 48 ** 3
+    for p in pr:  # every rank of a z-slab partition exchanges with its neighbours on every SpMV
+        assert p["halo_entries"] > 0 and p["send_entries"] > 0 and p["exchanges"] == 6 and p["allreduces"] == 12
+        assert p["neighbours"] >= 1 and p["interior_rows"] > 0 and p["rccl_ranks_seen"] == 0  # rehearsal: no RCCL

@@ -325,35 +325,95 @@ def test_fused_cg_history_vs_reference(ctx, key):
     cg.free()
 
 
-def test_full_size_hpcg256_properties(ctx):
-    """BASELINE metric size (HPCG 256^3, 449,455,096 nnz): size-independent
-    properties -- row sums in closed form, linearity, and the fused CG
-    history staying consistent with the unfused kernels."""
-    n1 = 256
+def unfused_cg_history(ctx, dA, b, x, iters, D=None):
+    """The reference's CG iteration (methods/cg.hpp:6-54, residual sample :162-166) call by call
+    through the kernel entry points, host scalars as in the reference: the unfused schedule."""
+    n = dA.n_rows
+    r, z, p, tmp = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    ctx.compute_residual(dA, x, b, r, tmp)                    # cg.hpp:100-118
+    ctx.apply_preconditioner("j" if D is not None else "none", n, None, None, D, None, None, None, z, r, tmp, tmp)
+    ctx.copy_vector(p, z)
+    hist = [ctx.euclidean_vec_norm(r)]
+    for _ in range(iters):
+        ctx.spmv(dA, p, tmp)                                  # :16
+        rz = ctx.dot(r, z)                                    # :19
+        alpha = rz / ctx.dot(tmp, p)                          # :23
+        ctx.sum_vectors(x, x, p, alpha)                       # :28
+        ctx.subtract_vectors(r, r, tmp, alpha)                # :31
+        ctx.apply_preconditioner("j" if D is not None else "none", n, None, None, D, None, None, None, z, r, tmp, tmp)
+        beta = ctx.dot(r, z) / rz                             # :47
+        ctx.sum_vectors(p, z, p, beta)                        # :52
+        hist.append(ctx.euclidean_vec_norm(r))                # :162-166
+    for v in (r, z, p, tmp):
+        v.free()
+    return np.array(hist)
+
+
+def hpcg_full_size_properties(ctx, n1, cg_iters):
+    """Size-independent properties of the HPCG operator and of the CG built on it, for sizes no CPU
+    oracle finishes (and, at 512^3, no reference CRS can hold): row sums and ||b - A x0|| in closed
+    form, linearity, symmetry, and the fused CG schedule against the unfused kernels."""
     dA = ctx.gen_hpcg(n1)
     N = n1 ** 3
     assert dA.nnz == (3 * n1 - 2) ** 3
+    assert dA.rp_width == (8 if dA.nnz >= 2 ** 31 - 8 else 4)
     ones, y = ctx.alloc(N), ctx.alloc(N)
     ctx.init_vector(ones, 1.0)
     ctx.spmv(dA, ones, y)
-    yh = y.to_host().reshape(n1, n1, n1)
     # A*1 = 26 - (neighbours) = 27 - cx*cy*cz
     c = np.full(n1, 3.0); c[0] = c[-1] = 2.0
     expect = 27.0 - c[:, None, None] * c[None, :, None] * c[None, None, :]
-    assert np.array_equal(yh, expect)
+    assert np.array_equal(y.to_host().reshape(n1, n1, n1), expect)
+    # r0 = b - A x0 with b = 1, x0 = 0.1 (solver.hpp:101-102): 1 - 0.1*(27 - cx cy cz) per row
+    vals, counts = np.unique(expect, return_counts=True)
+    r0_closed = float(np.sqrt(np.sum(counts * (1.0 - 0.1 * vals) ** 2)))
+    del expect
     rng = np.random.default_rng(1)
-    u, v = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N)
-    du, dv, dw = ctx.upload(u), ctx.upload(v), ctx.alloc(N)
-    yu, yv, yw = ctx.alloc(N), ctx.alloc(N), ctx.alloc(N)
+    du, dv, dw = ctx.upload(rng.uniform(-1, 1, N)), ctx.upload(rng.uniform(-1, 1, N)), ctx.alloc(N)
+    yu, yv = ctx.alloc(N), ctx.alloc(N)
     ctx.sum_vectors(dw, du, dv, -0.75)
-    ctx.spmv(dA, du, yu); ctx.spmv(dA, dv, yv); ctx.spmv(dA, dw, yw)
-    ctx.sum_vectors(yu, yu, yv, -0.75)
-    ctx.subtract_vectors(yu, yu, yw, 1.0)
-    assert ctx.euclidean_vec_norm(yu) <= 1e-13 * 52 * np.sqrt(N)
+    ctx.spmv(dA, du, yu); ctx.spmv(dA, dv, yv); ctx.spmv(dA, dw, y)
+    ctx.sum_vectors(ones, yu, yv, -0.75)
+    ctx.subtract_vectors(ones, ones, y, 1.0)
+    assert ctx.euclidean_vec_norm(ones) <= 1e-13 * 52 * np.sqrt(N)
     # symmetry: (Au, v) == (u, Av)
-    ctx.spmv(dA, du, yu); ctx.spmv(dA, dv, yv)
     a, b2 = ctx.dot(yu, dv), ctx.dot(du, yv)
     assert abs(a - b2) <= 1e-12 * max(abs(a), 1.0) * 10
+    for v in (du, dv, dw, yu, yv):
+        v.free()
+    # fused CG (bis_cg_*: 3 passes, device scalars) against the unfused kernels, same x0 and b
+    b, x = ones, y
+    ctx.init_vector(b, 1.0)
+    ctx.init_vector(x, 0.1)
+    cg = ctx.cg(dA, b, x)
+    r0 = cg.init(0.0)
+    assert abs(r0 - r0_closed) <= 1e-12 * r0_closed
+    cg.iterate(cg_iters)
+    iters, conv, hist = cg.status()
+    assert iters == cg_iters
+    x_fused = x.to_host()
+    cg.free()
+    ctx.init_vector(x, 0.1)
+    ref_hist = unfused_cg_history(ctx, dA, b, x, cg_iters)
+    assert abs(ref_hist[0] - r0_closed) <= 1e-12 * r0_closed
+    assert np.max(np.abs(hist - ref_hist)) <= 1e-10 * r0_closed
+    xu = x.to_host()
+    assert np.max(np.abs(x_fused - xu)) <= 1e-10 * np.max(np.abs(xu))
+    dA.free(); b.free(); x.free()
+
+
+def test_full_size_hpcg256_properties(ctx):
+    """BASELINE metric size (HPCG 256^3, 449,455,096 nnz): size-independent
+    properties -- row sums and ||r_0|| in closed form, linearity, symmetry, and the fused CG
+    history staying consistent with the unfused kernels (1e-10 r_0 over 25 iterations)."""
+    hpcg_full_size_properties(ctx, 256, 25)
+
+
+def test_full_size_hpcg512_target_properties(ctx):
+    """North-star target size (HPCG 512^3: 134,217,728 rows, 3,609,741,304 nnz > 2^31 -- int64
+    row pointers; the reference's CRS cannot hold it, so there is no oracle by construction):
+    the same size-independent gate on the RP = int64_t kernels at full size."""
+    hpcg_full_size_properties(ctx, 512, 12)
 
 
 def test_sptrsv_few_level_path_bit_exact(ctx, oracle):
@@ -622,3 +682,52 @@ def test_full_size_anderson256_properties(ctx):
         ctx.sum_vectors(t, t, yu)               # (D + T) x
         ctx.subtract_vectors(t, t, du)
         assert ctx.euclidean_vec_norm(t) <= 1e-13 * np.sqrt(N) * 20
+
+
+@pytest.mark.parametrize("kind,size", [("anderson", 24), ("hpcg", 12)])
+def test_sptrsv_lost_handoff_is_reported(ctx, oracle, kind, size):
+    """A hand-off that never arrives in the natural-order sweeps (lane-per-row kernel: 3 dependencies per
+    row; wave-per-row kernel: 13) must not hang and must not return NaNs silently: the waiting row gives
+    up after its bounded spin, the sweep finishes, and the next blocking call fails with BIS_ERR_SYNC.
+    Injected through the test hook `trsv_inject_loss` (one dependency of one row is redirected, for one
+    sweep, to a scratch slot nobody publishes).  The sweep after it is bit-exact again."""
+    from basic_iterative_solvers_amd import BisError
+    A = oracle.gen_hpcg(size) if kind == "hpcg" else oracle.gen_anderson(size, shift=9.0)
+    n = A.n_rows
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    dA = ctx.gen_hpcg(size) if kind == "hpcg" else ctx.gen_anderson(size, shift=9.0)
+    dLs, dUs, dD, dDinv = ctx.split_strict(dA)
+    b = np.random.default_rng(9).uniform(-1, 1, n)
+    db, x = ctx.upload(b), ctx.alloc(n)
+    want = oracle.sptrsv(Ls, D, b)
+    ctx.sptrsv(dLs, x, dD, db)               # builds the plan and the position table
+    assert np.array_equal(x.to_host(), want)
+    ctx.set_option("trsv_inject_loss", Ls.nnz // 2)
+    ctx.sptrsv(dLs, x, dD, db)
+    with pytest.raises(BisError, match="lost a hand-off"):
+        ctx.sync()
+    ctx.sync()                               # reported once
+    ctx.sptrsv(dLs, x, dD, db)
+    assert np.array_equal(x.to_host(), want)
+
+
+def test_sptrsv_wave_grid_is_capped_by_residency(ctx, oracle):
+    """The wave-per-row sweep deals rows to waves round robin and needs its whole grid resident: a
+    `trsv_grid` request far beyond what fits the device is capped by the occupancy query (not launched
+    as asked), so the result stays bit-exact instead of waiting for workgroups that never start."""
+    A = oracle.gen_fem(9, 8, 7)
+    n = A.n_rows
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    dLs, dUs, dD, dDinv = ctx.split_strict(ctx.gen_fem(9, 8, 7))
+    b = np.random.default_rng(10).uniform(-1, 1, n)
+    db, x = ctx.upload(b), ctx.alloc(n)
+    ctx.set_option("trsv_grid", 1 << 20)
+    try:
+        ctx.sptrsv(dLs, x, dD, db)
+        assert np.array_equal(x.to_host(), oracle.sptrsv(Ls, D, b))
+        ctx.bsptrsv(dUs, x, dD, db)
+        assert np.array_equal(x.to_host(), oracle.sptrsv(Us, D, b, backward=True))
+    finally:
+        ctx.set_option("trsv_grid", -1)

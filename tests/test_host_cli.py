@@ -204,3 +204,22 @@ def test_cli_is_linked_with_roctx():
     """The reference's LIKWID markers around spmv / sptrsv / backwards-sptrsv are roctx ranges here."""
     out = subprocess.run(["ldd", BIN], capture_output=True, text=True)
     assert "libroctx64" in out.stdout, out.stdout
+
+
+@pytest.mark.parametrize("mode,extra", [("mc", []), ("mc", ["-perm-host"]), ("rcm", []), ("bfs", [])])
+@pytest.mark.parametrize("name,solver,pc", [("hpcg_4x6x5", "cg", "none"), ("anderson8_shift9", "cg", "sgs"),
+                                            ("matrix_band_klein", "gs", "none")])
+def test_cli_perm_returns_x_star_in_natural_order(tmp_path, mode, extra, name, solver, pc):
+    """-perm solves P A P^T (Px) = P b; x* is handed back in the caller's row order (the reference's
+    SMAX path leaves it permuted, smax_helpers.hpp:44-80): it equals the x* of the un-permuted solve
+    to the accuracy both solves reach (stopping tolerance 1e-14 r0), not a permutation of it."""
+    f0, f1, fp = str(tmp_path / "x0.txt"), str(tmp_path / "x1.txt"), str(tmp_path / "perm.txt")
+    a = run_cli(name, solver, pc, {}, extra=["-dump-x", f0])
+    b = run_cli(name, solver, pc, {}, extra=["-perm", mode, "-dump-perm", fp, "-dump-x", f1] + extra)
+    assert a["converged"] and b["converged"]
+    x0, x1 = np.loadtxt(f0), np.loadtxt(f1)
+    perm = np.loadtxt(fp, dtype=np.int64)
+    assert not np.array_equal(perm, np.arange(len(perm)))  # the permutation is not trivial ...
+    scale = np.max(np.abs(x0))
+    assert np.max(np.abs(x1 - x0)) <= 1e-9 * scale         # ... and x* is back in natural order
+    assert np.max(np.abs(x1[perm] - x0)) > 1e-6 * scale    # (the permuted vector would not pass)
