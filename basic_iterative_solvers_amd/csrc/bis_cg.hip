@@ -43,13 +43,11 @@ struct bis_cg {
     double *p = nullptr, *r = nullptr, *z = nullptr, *tmp = nullptr;
     double *sc = nullptr;   // device scalars, see enum below
     double *pap_stage = nullptr; // [kPapBlocks] stage-1 sums of the SpMV's fused partials
-    int *flags = nullptr;   // device: [0] iters, [1] done, [2] converged
+    int *flags = nullptr;   // device: [0] iters, [1] done, [2] converged, [3] iteration at which the stop test fired
     double *hist = nullptr; // device residual history
     int hist_cap = 0;
     int enqueued = 0;
-    // one iteration captured as a hipGraph (single GPU, not while profiling): replayed by bis_cg_iterate
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_failed = false;
+    unsigned *counters = nullptr; // device: arrival tickets of the last-arriver reductions ([0] pap, [1] pass B)
 };
 
 namespace {
@@ -58,41 +56,99 @@ enum { S_RZ = 0, S_PAP, S_RZ_NEW, S_RR, S_ALPHA, S_BETA, S_STOP, S_COUNT = 8 }; 
 constexpr int kT = 256;
 constexpr int kMaxIters = 1 << 20;
 
-// pass B: x += alpha p; r -= alpha tmp; z = r/D (or r); partial (r,z), (r,r)
-template <bool JACOBI>
-__global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, const double *__restrict__ sc,
-                                                       const int *__restrict__ flags,
-                                                       const double *__restrict__ p,
+// ---- last-arriver reductions ---------------------------------------------------------
+// A streaming pass ends with a global reduction of per-workgroup partial sums.  Instead of a
+// second launch, every workgroup publishes its partials (write-through `sc1` stores, drained with
+// vmcnt(0) before the arrival is counted -- the "drained sc1 payload, then the flag" hand-off of
+// MI355X_MICROARCH.md, no release fence that would write back the pass' own dirty lines) and
+// takes a ticket; the workgroup that takes the LAST ticket re-reads all partials with L2-bypassing
+// loads and sums them in index order, so the result does not depend on which workgroup finishes
+// last: bit-reproducible like the two-launch form.
+__device__ __forceinline__ void publish(double *slot, double v) {
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fetch(const double *slot) {
+    return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// thread 0 only; returns true in the workgroup that arrives last (and re-arms the counter)
+__device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned n_groups) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the published partials have left this CU
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != n_groups - 1) return false;
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // next use: after a kernel boundary
+    return true;
+}
+
+// the scalar bookkeeping of one iteration (thread 0 of one workgroup): beta, the recorded
+// residual norm, the iteration count and the stopping test of solver.hpp:177-192
+__device__ __forceinline__ void cg_book(double rz_new, double rr, double *sc, int *flags, double *hist, int hist_cap) {
+    const double rz_old = sc[S_RZ];
+    sc[S_BETA] = rz_new / rz_old;          // cg.hpp:47
+    sc[S_RZ] = rz_new;
+    sc[S_RR] = rr;
+    const double norm = sqrt(rr);          // cg.hpp:164
+    const int it = flags[0] + 1;           // solver_harness.hpp:21
+    flags[0] = it;
+    if (it < hist_cap) hist[it] = norm;    // solver.hpp:161-163
+    // check_stopping_criteria, solver.hpp:177-192 (max_iters is the host's)
+    const bool conv = fabs(norm) < sc[S_STOP];
+    const bool diverged = fabs(norm) > DBL_MAX || norm != norm;
+    if (conv || diverged) { flags[1] = 1; flags[2] = conv ? 1 : 0; flags[3] = it; } // flags[3]: pass C of iteration `it` still updates x
+}
+
+// sc[S_PAP] = sum of the SpMV's fused per-wave partials (~1 M of them on HPCG-256): kPapBlocks
+// workgroups sum contiguous chunks, the last arriver sums the kPapBlocks chunk sums in order.
+constexpr int kPapBlocks = 256;
+__global__ __launch_bounds__(256) void cg_finish_pap_kernel(const double *__restrict__ partials, int n_partials,
+                                                            double *stage, double *sc, const int *flags,
+                                                            unsigned *counter) {
+    __shared__ double lds[4];
+    __shared__ bool last;
+    if (flags[1]) return;
+    const int per = (n_partials + kPapBlocks - 1) / kPapBlocks;
+    const int lo = blockIdx.x * per, hi = min(lo + per, n_partials);
+    double acc = 0.0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) acc += partials[i];
+    const double s = block_sum<256>(acc, lds);
+    if (threadIdx.x == 0) {
+        publish(stage + blockIdx.x, s);
+        last = arrive_last(counter, kPapBlocks);
+    }
+    __syncthreads();
+    if (!last) return;
+    const double t = block_sum<256>(threadIdx.x < kPapBlocks ? fetch(stage + threadIdx.x) : 0.0, lds);
+    if (threadIdx.x == 0) sc[S_PAP] = t;
+}
+
+// pass B: r -= alpha tmp; z = r/D (or r); (r,z), (r,r); the last workgroup reduces them and, on one
+// GPU, does the iteration's bookkeeping (DIST: the sums go through an all-reduce first, then cg_book_kernel).
+template <bool JACOBI, bool DIST>
+__global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, double *sc, int *flags,
                                                        const double *__restrict__ tmp,
                                                        const double *__restrict__ D,
-                                                       double *__restrict__ x,
                                                        double *__restrict__ r,
                                                        double *__restrict__ z,
-                                                       double *__restrict__ partials,
-                                                       size_t stride) {
+                                                       double *partials, size_t stride, unsigned *counter,
+                                                       double *hist, int hist_cap) {
     __shared__ double lds[kT / 64];
+    __shared__ bool last;
     if (flags[1]) return;
-    const double alpha = sc[S_RZ] / sc[S_PAP];
+    const double alpha = sc[S_RZ] / sc[S_PAP]; // cg.hpp:19-23
     const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kT;
     double rz = 0.0, rr = 0.0;
-    const double2 *p2 = reinterpret_cast<const double2 *>(p);
     const double2 *t2 = reinterpret_cast<const double2 *>(tmp);
     const double2 *D2 = reinterpret_cast<const double2 *>(D);
-    double2 *x2 = reinterpret_cast<double2 *>(x);
     double2 *r2 = reinterpret_cast<double2 *>(r);
     double2 *z2 = reinterpret_cast<double2 *>(z);
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n2; i += gs) {
-        const double2 pv = p2[i], tv = t2[i];
-        double2 xv = x2[i], rv = r2[i], zv;
-        xv.x = fma(alpha, pv.x, xv.x);
-        xv.y = fma(alpha, pv.y, xv.y);
-        rv.x = fma(-alpha, tv.x, rv.x);
+        const double2 tv = t2[i];
+        double2 rv = r2[i], zv;
+        rv.x = fma(-alpha, tv.x, rv.x);        // cg.hpp:31
         rv.y = fma(-alpha, tv.y, rv.y);
-        x2[i] = xv;
         r2[i] = rv;
         if (JACOBI) {
             const double2 dv = D2[i];
-            zv.x = rv.x / (1.0 * dv.x);
+            zv.x = rv.x / (1.0 * dv.x);        // kernels.hpp:151
             zv.y = rv.y / (1.0 * dv.y);
             z2[i] = zv;
         } else {
@@ -105,9 +161,7 @@ __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, const double *
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double xv = fma(alpha, p[i], x[i]);
         const double rv = fma(-alpha, tmp[i], r[i]);
-        x[i] = xv;
         r[i] = rv;
         double zv = rv;
         if (JACOBI) { zv = rv / (1.0 * D[i]); z[i] = zv; }
@@ -117,88 +171,61 @@ __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, const double *
     const double s0 = block_sum<kT>(rz, lds);
     __syncthreads();
     const double s1 = block_sum<kT>(rr, lds);
-    if (threadIdx.x == 0) { partials[blockIdx.x] = s0; partials[stride + blockIdx.x] = s1; }
-}
-
-// sc[S_PAP] = sum of the SpMV's fused per-row-block partials (one per 2048
-// non-zeros: 219k of them on HPCG-256), in two fixed-order stages.
-constexpr int kPapBlocks = 128;
-__global__ __launch_bounds__(256) void cg_finish_pap_stage1(const double *partials, int n_partials,
-                                                            double *stage, const int *flags) {
-    __shared__ double lds[4];
-    if (flags[1]) return;
-    const int per = (n_partials + kPapBlocks - 1) / kPapBlocks;
-    const int lo = blockIdx.x * per, hi = min(lo + per, n_partials);
-    double acc = 0.0;
-    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) acc += partials[i];
-    const double s = block_sum<256>(acc, lds);
-    if (threadIdx.x == 0) stage[blockIdx.x] = s;
-}
-__global__ __launch_bounds__(kPapBlocks) void cg_finish_pap_stage2(const double *stage, double *sc,
-                                                                   const int *flags) {
-    __shared__ double lds[kPapBlocks / 64];
-    if (flags[1]) return;
-    const double s = block_sum<kPapBlocks>(stage[threadIdx.x], lds);
-    if (threadIdx.x == 0) sc[S_PAP] = s;
-}
-
-// reduce (r,z), (r,r); record the residual norm; beta; stop test.
-// REDUCE: sum the per-block partials into sc[S_RZ_NEW], sc[S_RR];
-// BOOK: the scalar bookkeeping.  Single GPU runs both in one launch; the
-// distributed schedule puts the all-reduce of the two sums in between.
-template <bool REDUCE, bool BOOK>
-__global__ __launch_bounds__(256) void cg_scalars_kernel(const double *partials, int n_partials,
-                                                         size_t stride, double *sc, int *flags,
-                                                         double *hist, int hist_cap) {
-    __shared__ double lds[4];
-    if (flags[1]) return;
-    double rz_new = 0.0, rr = 0.0;
-    if (REDUCE) {
-        double a0 = 0.0, a1 = 0.0;
-        for (int i = threadIdx.x; i < n_partials; i += 256) { a0 += partials[i]; a1 += partials[stride + i]; }
-        rz_new = block_sum<256>(a0, lds);
-        __syncthreads();
-        rr = block_sum<256>(a1, lds);
-        if (!BOOK && threadIdx.x == 0) { sc[S_RZ_NEW] = rz_new; sc[S_RR] = rr; }
+    if (threadIdx.x == 0) {
+        publish(partials + blockIdx.x, s0);
+        publish(partials + stride + blockIdx.x, s1);
+        last = arrive_last(counter, gridDim.x);
     }
-    if (BOOK && threadIdx.x == 0) {
-        if (!REDUCE) { rz_new = sc[S_RZ_NEW]; rr = sc[S_RR]; }
-        const double rz_old = sc[S_RZ];
-        sc[S_BETA] = rz_new / rz_old;          // cg.hpp:47
-        sc[S_RZ] = rz_new;
-        sc[S_RR] = rr;
-        const double norm = sqrt(rr);          // cg.hpp:164
-        const int it = flags[0] + 1;           // solver_harness.hpp:21
-        flags[0] = it;
-        if (it < hist_cap) hist[it] = norm;    // solver.hpp:161-163
-        // check_stopping_criteria, solver.hpp:177-192 (max_iters is the host's)
-        const bool conv = fabs(norm) < sc[S_STOP];
-        const bool diverged = fabs(norm) > DBL_MAX || norm != norm;
-        if (conv || diverged) { flags[1] = 1; flags[2] = conv ? 1 : 0; }
+    __syncthreads();
+    if (!last) return;
+    // every other workgroup has read sc[S_RZ] / sc[S_PAP] before it arrived: the scalars may change now
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kT) { a0 += fetch(partials + i); a1 += fetch(partials + stride + i); }
+    const double rz_new = block_sum<kT>(a0, lds);
+    __syncthreads();
+    const double rr_new = block_sum<kT>(a1, lds);
+    if (threadIdx.x == 0) {
+        sc[S_ALPHA] = alpha;                   // pass C applies it to x
+        if (DIST) { sc[S_RZ_NEW] = rz_new; sc[S_RR] = rr_new; }
+        else cg_book(rz_new, rr_new, sc, flags, hist, hist_cap);
     }
 }
 
-// pass C: p = z + beta p   (None: z == r)
+// distributed schedule: the bookkeeping after the all-reduce of {(r,z), (r,r)}
+__global__ void cg_book_kernel(double *sc, int *flags, double *hist, int hist_cap) {
+    if (flags[1]) return;
+    if (threadIdx.x == 0) cg_book(sc[S_RZ_NEW], sc[S_RR], sc, flags, hist, hist_cap);
+}
+
+// pass C: x += alpha p (cg.hpp:28, deferred to here: p is read once for both updates, 8 N bytes
+// less per iteration than updating x in pass B); p = z + beta p (cg.hpp:52; None: z == r).
+// `it` = the iteration this launch belongs to: when the stop test fired in THIS iteration the x
+// update still runs (the reference updates x before it samples the residual), later launches are no-ops.
 __global__ __launch_bounds__(kT) void cg_p_update_kernel(int64_t n, const double *__restrict__ sc,
-                                                         const int *__restrict__ flags,
+                                                         const int *__restrict__ flags, int it,
                                                          const double *__restrict__ z,
+                                                         double *__restrict__ x,
                                                          double *__restrict__ p) {
-    // NOTE: runs even when the stop test has just fired in this iteration --
-    // the reference also forms p_new before it checks (cg.hpp:52); p is not
-    // part of the result, so skipping it is equivalent and cheaper.
-    if (flags[1]) return;
-    const double beta = sc[S_BETA];
+    if (flags[1] && flags[3] != it) return;
+    const double alpha = sc[S_ALPHA], beta = sc[S_BETA];
     const int64_t n2 = n >> 1, gs = (int64_t)gridDim.x * kT;
     const double2 *z2 = reinterpret_cast<const double2 *>(z);
     double2 *p2 = reinterpret_cast<double2 *>(p);
+    double2 *x2 = reinterpret_cast<double2 *>(x);
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n2; i += gs) {
         const double2 zv = z2[i];
-        double2 pv = p2[i];
+        double2 pv = p2[i], xv = x2[i];
+        xv.x = fma(alpha, pv.x, xv.x);
+        xv.y = fma(alpha, pv.y, xv.y);
         pv.x = fma(beta, pv.x, zv.x);
         pv.y = fma(beta, pv.y, zv.y);
+        x2[i] = xv;
         p2[i] = pv;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = fma(beta, p[n - 1], z[n - 1]);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        x[n - 1] = fma(alpha, p[n - 1], x[n - 1]);
+        p[n - 1] = fma(beta, p[n - 1], z[n - 1]);
+    }
 }
 
 inline int grid_for(int64_t n) {
@@ -228,9 +255,11 @@ static bis_status cg_create_common(bis_ctx *ctx, bis_dist *dist, const bis_mat *
     if (st == BIS_OK && A_D) st = bis_vec_alloc(ctx, cg->n, &cg->z);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->n, &cg->tmp);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, S_COUNT, &cg->sc);
-    if (st == BIS_OK) st = bis_vec_alloc(ctx, 256, &cg->pap_stage);
+    if (st == BIS_OK) st = bis_vec_alloc(ctx, kPapBlocks, &cg->pap_stage);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->hist_cap, &cg->hist);
     if (st == BIS_OK && hipMalloc(&cg->flags, sizeof(int) * 4) != hipSuccess) st = BIS_ERR_HIP;
+    if (st == BIS_OK && (hipMalloc(&cg->counters, sizeof(unsigned) * 4) != hipSuccess ||
+                         hipMemsetAsync(cg->counters, 0, sizeof(unsigned) * 4, ctx->stream) != hipSuccess)) st = BIS_ERR_HIP;
     if (st != BIS_OK) { bis_cg_destroy(ctx, cg); return st; }
     if (!A_D) cg->z = cg->r; // z aliases r without a preconditioner
     *out = cg;
@@ -264,7 +293,7 @@ bis_status bis_cg_destroy(bis_ctx *ctx, bis_cg *cg) {
     hipFree(cg->pap_stage);
     hipFree(cg->hist);
     hipFree(cg->flags);
-    if (cg->graph_exec) hipGraphExecDestroy(cg->graph_exec);
+    hipFree(cg->counters);
     delete cg;
     return BIS_OK;
 }
@@ -308,46 +337,35 @@ bis_status bis_cg_init(bis_ctx *ctx, bis_cg *cg, double tol, double *r0_norm_hos
     return BIS_OK;
 }
 
-// one CG iteration enqueued on ctx->stream (also the body that is captured into the hipGraph)
-static bis_status cg_enqueue_iteration(bis_ctx *ctx, bis_cg *cg, int g) {
+// one CG iteration enqueued on ctx->stream: 4 launches on one GPU (SpMV with the fused (Ap,p) partials,
+// their two-stage sum, pass B with the reductions and the bookkeeping in its last workgroup, pass C)
+static bis_status cg_enqueue_iteration(bis_ctx *ctx, bis_cg *cg, int g, int it) {
     const int64_t n = cg->n;
     int n_part = 0;
     bis_status st;
     if (cg->dist) st = bis_dist_spmv_launch(ctx, cg->dist, cg->p, cg->tmp, cg->p, &n_part);
     else st = bis_spmv_launch(ctx, cg->A, cg->p, cg->tmp, cg->p, &n_part);
     if (st != BIS_OK) return st;
-    hipLaunchKernelGGL(cg_finish_pap_stage1, dim3(kPapBlocks), dim3(256), 0, ctx->stream,
-                       ctx->partials, n_part, cg->pap_stage, cg->flags);
-    hipLaunchKernelGGL(cg_finish_pap_stage2, dim3(1), dim3(kPapBlocks), 0, ctx->stream,
-                       cg->pap_stage, cg->sc, cg->flags);
+    hipLaunchKernelGGL(cg_finish_pap_kernel, dim3(kPapBlocks), dim3(256), 0, ctx->stream,
+                       ctx->partials, n_part, cg->pap_stage, cg->sc, cg->flags, cg->counters);
     if (cg->dist) {
         st = bis_dist_allreduce(ctx, cg->dist, cg->sc + S_PAP, 1);
         if (st != BIS_OK) return st;
     }
-    if (cg->A_D)
-        hipLaunchKernelGGL(cg_update_kernel<true>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc,
-                           cg->flags, cg->p, cg->tmp, cg->A_D, cg->x, cg->r, cg->z, ctx->partials,
-                           (size_t)kMaxReduceBlocks);
-    else
-        hipLaunchKernelGGL(cg_update_kernel<false>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc,
-                           cg->flags, cg->p, cg->tmp, cg->A_D, cg->x, cg->r, cg->z, ctx->partials,
-                           (size_t)kMaxReduceBlocks);
+#define BIS_CG_UPDATE(J, D)                                                                                  \
+    hipLaunchKernelGGL((cg_update_kernel<J, D>), dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags,    \
+                       cg->tmp, cg->A_D, cg->r, cg->z, ctx->partials, (size_t)kMaxReduceBlocks,              \
+                       cg->counters + 1, cg->hist, cg->hist_cap)
+    if (cg->dist) { if (cg->A_D) BIS_CG_UPDATE(true, true); else BIS_CG_UPDATE(false, true); }
+    else { if (cg->A_D) BIS_CG_UPDATE(true, false); else BIS_CG_UPDATE(false, false); }
+#undef BIS_CG_UPDATE
     if (cg->dist) {
-        hipLaunchKernelGGL((cg_scalars_kernel<true, false>), dim3(1), dim3(256), 0, ctx->stream,
-                           ctx->partials, g, (size_t)kMaxReduceBlocks, cg->sc, cg->flags, cg->hist,
-                           cg->hist_cap);
         st = bis_dist_allreduce(ctx, cg->dist, cg->sc + S_RZ_NEW, 2); // {(r,z),(r,r)} batched
         if (st != BIS_OK) return st;
-        hipLaunchKernelGGL((cg_scalars_kernel<false, true>), dim3(1), dim3(64), 0, ctx->stream,
-                           ctx->partials, g, (size_t)kMaxReduceBlocks, cg->sc, cg->flags, cg->hist,
-                           cg->hist_cap);
-    } else {
-        hipLaunchKernelGGL((cg_scalars_kernel<true, true>), dim3(1), dim3(256), 0, ctx->stream,
-                           ctx->partials, g, (size_t)kMaxReduceBlocks, cg->sc, cg->flags, cg->hist,
-                           cg->hist_cap);
+        hipLaunchKernelGGL(cg_book_kernel, dim3(1), dim3(64), 0, ctx->stream, cg->sc, cg->flags, cg->hist, cg->hist_cap);
     }
-    hipLaunchKernelGGL(cg_p_update_kernel, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags,
-                       cg->z, cg->p);
+    hipLaunchKernelGGL(cg_p_update_kernel, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags, it,
+                       cg->z, cg->x, cg->p);
     return BIS_OK;
 }
 
@@ -363,39 +381,10 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
     if (st != BIS_OK) return st;
     ctx->spmv_stop = cg->flags;
     struct StopGuard { bis_ctx *c; ~StopGuard() { c->spmv_stop = nullptr; } } stop_guard{ctx};
-    int done = 0;
-    // Launch-bound sizes: the 7 launches of an iteration are captured once as a hipGraph and replayed
-    // (single GPU; not while the per-launch HIP events of bis_profile_enable are wanted).  The first
-    // iteration of a solver runs eagerly so that lazily built structures exist before the capture.
-    // Opt-in (cg_graph=1): measured no gain on ROCm 7.2 -- HPCG-32/64/128/256: 2.33/4.83/40.6/607 ms of plain
-    // launches against 2.66/5.73/42.8/588 ms of graph replays.
-    const bool want_graph = !cg->dist && !ctx->profile && !cg->graph_failed && bis_opts().cg_graph > 0 &&
-                            (cg->graph_exec || n_iters >= 3);
-    if (want_graph) {
-        if (!cg->graph_exec) {
-            st = cg_enqueue_iteration(ctx, cg, g);
-            if (st != BIS_OK) return st;
-            ++done;
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
-            if (e == hipSuccess) {
-                st = cg_enqueue_iteration(ctx, cg, g);
-                e = hipStreamEndCapture(ctx->stream, &graph);
-                if (st == BIS_OK && e == hipSuccess && graph) e = hipGraphInstantiate(&cg->graph_exec, graph, nullptr, nullptr, 0);
-                else if (e == hipSuccess) e = hipErrorUnknown;
-                if (graph) hipGraphDestroy(graph);
-            }
-            if (e != hipSuccess || !cg->graph_exec) { // not capturable here: stay with plain launches
-                (void)hipGetLastError();
-                cg->graph_exec = nullptr;
-                cg->graph_failed = true;
-            }
-        }
-        if (cg->graph_exec)
-            for (; done < n_iters; ++done) BIS_HIP_CHECK(ctx, hipGraphLaunch(cg->graph_exec, ctx->stream));
-    }
-    for (; done < n_iters; ++done) {
-        st = cg_enqueue_iteration(ctx, cg, g);
+    // (replaying a captured iteration as a hipGraph was measured and removed: no gain on ROCm 7.2 --
+    // HPCG-32/64/128/256: 2.33/4.83/40.6/607 ms of plain launches against 2.66/5.73/42.8/588 ms of replays)
+    for (int done = 0; done < n_iters; ++done) {
+        st = cg_enqueue_iteration(ctx, cg, g, cg->enqueued + done + 1);
         if (st != BIS_OK) return st;
     }
     BIS_HIP_CHECK(ctx, hipGetLastError());

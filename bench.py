@@ -253,7 +253,7 @@ def main():
         except Exception:
             traffic = None
     stream = measured_stream(ctx, N)
-    fused_bytes = 12 * nnz + (108 if args.precond == "j" else 92) * N
+    fused_bytes = 12 * nnz + (100 if args.precond == "j" else 84) * N  # SpMV 20 N, pass B 24 N (+16 N Jacobi), pass C 40 N
     out = {
         "metric": "CG iterations/sec + SpMV GFLOP/s (% HBM roofline), HPCG 256^3 at 1/2/4/8 GPUs",
         "value": its, "unit": "CG iterations/s", "n_gpus": 1, "steps": args.steps,
