@@ -200,6 +200,9 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_TUNE_PLACEMENT")) v.tune_placement = atoi(e);
         if (const char *e = getenv("BIS_CG_GRAPH")) v.cg_graph = atoi(e);
         if (const char *e = getenv("BIS_FORCE_RP64")) v.force_rp64 = atoi(e);
+        if (const char *e = getenv("BIS_TRSV_TILED")) v.trsv_tiled = atoi(e);
+        if (const char *e = getenv("BIS_TRSV_TILE_ROWS")) v.trsv_tile_rows = atoi(e);
+        if (const char *e = getenv("BIS_TRSV_TILE_WGS")) v.trsv_tile_wgs = atoi(e);
         return v;
     }();
     return o;
@@ -229,6 +232,9 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "tune_placement")) o.tune_placement = value;
     else if (!strcmp(name, "cg_graph")) o.cg_graph = value;
     else if (!strcmp(name, "force_rp64")) o.force_rp64 = value;
+    else if (!strcmp(name, "trsv_tiled")) o.trsv_tiled = value;
+    else if (!strcmp(name, "trsv_tile_rows")) o.trsv_tile_rows = value;
+    else if (!strcmp(name, "trsv_tile_wgs")) o.trsv_tile_wgs = value;
     else if (!strcmp(name, "dist_host_plan")) o.dist_host_plan = value;
     else if (!strcmp(name, "trsv_inject_loss")) o.trsv_inject_loss = value;
     else return BIS_ERR_INVALID;

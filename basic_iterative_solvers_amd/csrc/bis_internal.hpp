@@ -77,6 +77,9 @@ struct bis_options {
     int spmv_lds_pad = -1; // diagnostic: extra dynamic LDS bytes per workgroup (lowers occupancy)
     int spmv_packed = -1;  // 16-bit packed column stream: 0 off, 1 select tree, 2 lane permute (-1: default = 1)
     int dist_host_plan = -1; // 1: bis_dist_create plans the halo on the host from the downloaded structure (default: on the device)
+    int trsv_tiled = -1;    // natural-order sweeps: 0 level-scheduled kernels of round 1, 1 (default) tiled sweep (bis_trsv_tiled.hip)
+    int trsv_tile_rows = -1; // rows per tile (default 2048)
+    int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
     int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes
 };
@@ -248,6 +251,11 @@ void bis_mat_free_meta(bis_mat *A);
 void bis_trsv_plan_destroy(bis_trsv_plan *p);
 bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
                                      bis_mat **U_strict, double *D, double *D_inv, bool check_diag);
+// tiled natural-order sweep (bis_trsv_tiled.hip); *out stays null when the matrix does not qualify
+struct bis_trsv_tiled;
+bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_tiled **out);
+bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, const double *D, const double *b);
+void bis_trsv_tiled_destroy(bis_trsv_tiled *p);
 // device-side level analysis of a strictly triangular matrix (bis_analysis.hip)
 bis_status bis_trsv_analyse_device(bis_ctx *ctx, const bis_mat *T, bool backward, int32_t *perm_dev,
                                    std::vector<int64_t> &level_ptr, int &n_levels, int64_t &max_width,

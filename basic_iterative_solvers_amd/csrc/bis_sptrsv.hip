@@ -51,6 +51,9 @@ struct bis_trsv_plan {
     // few-level orderings whose levels are contiguous row ranges: one row view per level
     std::vector<bis_mat *> level_views;
     std::vector<int64_t> level_row0;
+    // natural orderings: the tiled sweep (bis_trsv_tiled.hip), built at the first solve
+    bis_trsv_tiled *tiled = nullptr;
+    bool tiled_tried = false;
 };
 
 void bis_trsv_plan_destroy(bis_trsv_plan *p) {
@@ -59,6 +62,7 @@ void bis_trsv_plan_destroy(bis_trsv_plan *p) {
     hipFree(p->xs);
     hipFree(p->pcol);
     hipFree(p->ticket);
+    bis_trsv_tiled_destroy(p->tiled);
     for (bis_mat *v : p->level_views) { // row views: only their block tables are theirs
         bis_mat_free_meta(v);
         delete v;
@@ -519,6 +523,14 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
         }
         BIS_HIP_CHECK(ctx, hipGetLastError());
         return BIS_OK;
+    }
+    if (bis_opts().trsv_tiled != 0 && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_one_xcd <= 0) {
+        if (!p->tiled_tried) {
+            p->tiled_tried = true;
+            st = bis_trsv_tiled_build(ctx, T, backward, &p->tiled);
+            if (st != BIS_OK) return st;
+        }
+        if (p->tiled) return bis_trsv_tiled_solve(ctx, p->tiled, x, D, b);
     }
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,
