@@ -28,6 +28,7 @@
 #include "bis_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 struct bis_trsv_tiled {
@@ -42,7 +43,7 @@ struct bis_trsv_tiled {
     int64_t *tile_ent0 = nullptr;   // [n_tiles + 1]
     int64_t *tile_ext0 = nullptr;   // [n_tiles + 1]
     double *ent_val = nullptr;      // [n_ent]  entries per step, k-major / lane-minor (padded to the step's longest row)
-    int32_t *ent_code = nullptr;    // [n_ent]  >= 0: in-tile operand (slot relative to the tile); < 0: -(1 + external ordinal)
+    int32_t *ent_code = nullptr;    // [n_ent]  operand index: < kMaxB the tile's own slot, else kMaxB + external ordinal
     int32_t *ext_src = nullptr;     // [n_ext]  slot (global) whose published result the ordinal stands for
     unsigned long long *xs = nullptr; // [n + 1] published results, by slot
     unsigned *ticket = nullptr;
@@ -71,11 +72,20 @@ constexpr unsigned kSpinMem = 1u << 22;  // polls of a memory word
 
 enum { C_TICKET = 0, C_ENT_LOADED, C_ENT_DONE, C_SLOT_LOADED, C_SLOT_DONE, C_N = 8 };
 
+// Hand-offs between the waves of one workgroup go through LDS words.  The LDS executes one wave's
+// operations in issue order, so "data writes, then the watermark write" needs no wait in between, and a
+// reader that has SEEN the watermark reads the data behind it; all the code has to prevent is the compiler
+// moving LDS accesses across the watermark access (the empty asm statements).  C++ release/acquire at
+// workgroup scope would be correct too but also drains the wave's outstanding GLOBAL stores
+// (s_waitcnt vmcnt(0): a memory round trip per step -- measured 25 ms instead of 1 ms per sweep).
 __device__ __forceinline__ unsigned lds_acquire(const unsigned *p) {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return v;
 }
 __device__ __forceinline__ void lds_release(unsigned *p, unsigned v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned long long *xs, int64_t n) {
@@ -108,11 +118,15 @@ struct TiledArgs {
     unsigned *fault;
     int64_t n;
     int B, n_tiles;
+    long long *dbg; // optional, 8 words per tile: start, end (s_memtime), cycles the compute wave waited for the loaders /
+                    // for external operands, end of the entry loader / slot loader / poller, steps
 };
 
 __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
-    __shared__ double x_loc[kMaxB];
-    __shared__ unsigned long long ext_val[kMaxExt];
+    // operands of the tile's rows: [0, kMaxB) results of the tile itself, by slot; [kMaxB, kMaxB + kMaxExt) the
+    // external operands, by ordinal (sentinel until the poller delivers them).  The entry codes index this
+    // array directly: one LDS read per operand, no branch on where it comes from.
+    __shared__ unsigned long long opnd[kMaxB + kMaxExt];
     __shared__ double ring_val[kRingEnt];
     __shared__ int ring_code[kRingEnt];
     __shared__ int2 ring_rowlen[kRingSlot];
@@ -133,9 +147,11 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
         const int n_ent = (int)(a.tile_ent0[t + 1] - ent0);
         const int64_t ext0 = a.tile_ext0[t];
         const int n_ext = (int)(a.tile_ext0[t + 1] - ext0);
-        for (int e = threadIdx.x; e < n_ext; e += 256) ext_val[e] = kSentinel;
+        for (int e = threadIdx.x; e < n_ext; e += 256) opnd[kMaxB + e] = kSentinel;
         __syncthreads();
 
+        const long long t_start = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+        long long w_load = 0, w_ext = 0;
         if (wave == 0) {
             // ---- compute wave: one lane per row of the step, CRS-order fma chain ----
             int2 d_cur = a.step_desc[sd0 + min(lane, n_steps)];
@@ -154,10 +170,12 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 const int L = w > 0 ? (ent_e - ent_b) / w : 0;
                 // the loaders have to be past this step
                 unsigned spins = 0;
+                const long long t0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
                 while ((int)lds_acquire(&ctl[C_ENT_LOADED]) < ent_e || (int)lds_acquire(&ctl[C_SLOT_LOADED]) < slot_e) {
                     if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (a.dbg) w_load += (long long)__builtin_readcyclecounter() - t0;
                 const bool active = lane < w;
                 const int sl = (slot_b + lane) & (kRingSlot - 1);
                 const int2 rl = active ? ring_rowlen[sl] : make_int2(0, 0);
@@ -179,24 +197,23 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                         v[q] = on[q] ? ring_val[idx] : 0.0;
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (code[q] >= 0) bits[q] = (unsigned long long)__double_as_longlong(x_loc[code[q]]);
-                        else bits[q] = *(const volatile unsigned long long *)&ext_val[-1 - code[q]];
-                    }
+                    for (int q = 0; q < 4; ++q) bits[q] = __hip_atomic_load(&opnd[code[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     // wait (whole wave, LDS only) until the poller has delivered the external operands of this round
                     unsigned sp2 = 0;
+                    const long long t1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
                     for (;;) {
                         bool pend = false;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) pend |= on[q] && code[q] < 0 && bits[q] == kSentinel;
+                        for (int q = 0; q < 4; ++q) pend |= on[q] && bits[q] == kSentinel; // results of the tile are never the sentinel
                         if (!__ballot(pend)) break;
                         if (++sp2 > kSpinLds) { lost = true; break; }
                         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (on[q] && code[q] < 0 && bits[q] == kSentinel)
-                                bits[q] = *(const volatile unsigned long long *)&ext_val[-1 - code[q]];
+                            if (on[q] && bits[q] == kSentinel)
+                                bits[q] = __hip_atomic_load(&opnd[code[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                    if (a.dbg) w_ext += (long long)__builtin_readcyclecounter() - t1;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (on[q]) acc = fma(v[q], __longlong_as_double((long long)bits[q]), acc);
@@ -206,11 +223,15 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 if (res != res || lost) out = kCanonNaN; // never publish the sentinel pattern
                 if (lost && lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (active) {
-                    x_loc[slot_b + lane] = __longlong_as_double((long long)out);
+                    __hip_atomic_store(&opnd[slot_b + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     a.x[rl.x] = __longlong_as_double((long long)out);
                     __hip_atomic_store(&a.xs[slot0 + slot_b + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (lane == 0) { lds_release(&ctl[C_ENT_DONE], (unsigned)ent_e); lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_e); }
+            }
+            if (a.dbg && lane == 0) {
+                long long *d = a.dbg + (int64_t)t * 8;
+                d[0] = t_start; d[1] = (long long)__builtin_readcyclecounter(); d[2] = w_load; d[3] = w_ext; d[7] = n_steps;
             }
         } else if (wave == 1) {
             // ---- entry loader: the tile's entry stream (step order, k-major / lane-minor) into the ring ----
@@ -241,6 +262,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 done += chunk;
                 lds_release(&ctl[C_ENT_LOADED], (unsigned)done);
             }
+            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 4] = (long long)__builtin_readcyclecounter();
         } else if (wave == 2) {
             // ---- per-row operand loader: row index, row length, b[row], D[row] in slot order ----
             constexpr int U = kSlotChunk / 64;
@@ -277,6 +299,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 done += chunk;
                 lds_release(&ctl[C_SLOT_LOADED], (unsigned)done);
             }
+            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 5] = (long long)__builtin_readcyclecounter();
         } else {
             // ---- poller: external operands in first-need order; every lane advances on its own ----
             int e = lane;
@@ -289,7 +312,8 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     const bool give_up = ++spins > kSpinMem;
                     if (vbits != kSentinel || give_up) {
                         if (give_up) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        ext_val[e] = give_up && vbits == kSentinel ? kCanonNaN : vbits;
+                        __hip_atomic_store(&opnd[kMaxB + e], give_up && vbits == kSentinel ? kCanonNaN : vbits, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
                         e += 64;
                         src = src_next;
                         src_next = e + 64 < n_ext ? a.ext_src[ext0 + e + 64] : 0;
@@ -298,6 +322,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
+            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 6] = (long long)__builtin_readcyclecounter();
         }
         __syncthreads();
     }
@@ -400,7 +425,7 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                                     ext_ord[(size_t)gs] = n_ext_tile++;
                                     ext_src.push_back(gs);
                                 }
-                                ent_code.push_back(-1 - ext_ord[(size_t)gs]);
+                                ent_code.push_back(kMaxB + ext_ord[(size_t)gs]);
                             }
                         }
                     s += w;
@@ -462,10 +487,24 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, p->xs, p->n + 1);
     BIS_HIP_CHECK(ctx, hipMemsetAsync(p->ticket, 0, sizeof(unsigned) * 4, ctx->stream));
     TiledArgs a{p->slot_rowlen, p->step_desc, p->tile_step0, p->tile_ent0, p->tile_ext0, p->ent_val, p->ent_code,
-                p->ext_src, p->xs, p->ticket, D, b, x, ctx->fault_dev, p->n, p->B, p->n_tiles};
+                p->ext_src, p->xs, p->ticket, D, b, x, ctx->fault_dev, p->n, p->B, p->n_tiles, nullptr};
+    static long long *dbg_buf = nullptr; // diagnostic (BIS_TRSV_TILE_DEBUG=file): per-tile cycle stamps of the last sweep
+    static int64_t dbg_cap = 0;
+    const char *dbg_file = getenv("BIS_TRSV_TILE_DEBUG");
+    if (dbg_file) {
+        if (dbg_cap < p->n_tiles) { hipFree(dbg_buf); hipMalloc(&dbg_buf, sizeof(long long) * 8 * (size_t)p->n_tiles); dbg_cap = p->n_tiles; }
+        hipMemsetAsync(dbg_buf, 0, sizeof(long long) * 8 * (size_t)p->n_tiles, ctx->stream);
+        a.dbg = dbg_buf;
+    }
     int per_cu = bis_opts().trsv_tile_wgs > 0 ? bis_opts().trsv_tile_wgs : 2;
     const int grid = (int)std::min<int64_t>(p->n_tiles, (int64_t)ctx->n_cus * per_cu);
     hipLaunchKernelGGL(trsv_tiled_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
     BIS_HIP_CHECK(ctx, hipGetLastError());
+    if (dbg_file) {
+        std::vector<long long> h((size_t)p->n_tiles * 8);
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpy(h.data(), dbg_buf, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(dbg_file, "wb")) { fwrite(h.data(), sizeof(long long), h.size(), f); fclose(f); }
+    }
     return BIS_OK;
 }
