@@ -38,12 +38,12 @@ struct bis_trsv_tiled {
     int64_t n_steps = 0, n_ent = 0, n_ext = 0;
     // device arrays
     int2 *slot_rowlen = nullptr;    // [n]      slot -> {row, number of entries}; slots = rows in (tile, local level, order) order
-    int2 *step_desc = nullptr;      // [n_steps + n_tiles] per tile: {first slot, first entry} of each step, relative to the tile, + end marker
+    int2 *step_desc = nullptr;      // [n_steps + n_tiles] per tile: {first slot | longest row << 16, first entry} of each step, relative to the tile, + end marker
     int64_t *tile_step0 = nullptr;  // [n_tiles + 1] index into step_desc (tile t owns [tile_step0[t], tile_step0[t+1]) incl. its end marker)
     int64_t *tile_ent0 = nullptr;   // [n_tiles + 1]
     int64_t *tile_ext0 = nullptr;   // [n_tiles + 1]
     double *ent_val = nullptr;      // [n_ent]  entries per step, k-major / lane-minor (padded to the step's longest row)
-    int32_t *ent_code = nullptr;    // [n_ent]  operand index: < kMaxB the tile's own slot, else kMaxB + external ordinal
+    int32_t *ent_code = nullptr;    // [n_ent]  operand index: < B the tile's own slot, else B + external ordinal
     int32_t *ext_src = nullptr;     // [n_ext]  slot (global) whose published result the ordinal stands for
     unsigned long long *xs = nullptr; // [n + 1] published results, by slot
     unsigned *ticket = nullptr;
@@ -61,8 +61,8 @@ namespace {
 
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload (same as bis_sptrsv.hip)
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
-constexpr int kMaxB = 2048;       // rows per tile (LDS: 16 KiB of results)
-constexpr int kMaxExt = 2048;     // distinct external operands per tile (LDS: 16 KiB)
+constexpr int kMaxB = 2048;       // rows per tile
+constexpr int kOpnd = 4096;       // operands of a tile in LDS (32 KiB): its own B results + its distinct external operands
 constexpr int kRingEnt = 2048;    // entry ring (LDS: 16 + 8 KiB)
 constexpr int kRingSlot = 256;    // per-row operand ring (LDS: 2 + 4 KiB)
 constexpr int kEntChunk = 1024;   // entries per loader round (16 per lane)
@@ -123,10 +123,10 @@ struct TiledArgs {
 };
 
 __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
-    // operands of the tile's rows: [0, kMaxB) results of the tile itself, by slot; [kMaxB, kMaxB + kMaxExt) the
+    // operands of the tile's rows: [0, B) results of the tile itself, by slot; [B, kOpnd) the
     // external operands, by ordinal (sentinel until the poller delivers them).  The entry codes index this
     // array directly: one LDS read per operand, no branch on where it comes from.
-    __shared__ unsigned long long opnd[kMaxB + kMaxExt];
+    __shared__ unsigned long long opnd[kOpnd];
     __shared__ double ring_val[kRingEnt];
     __shared__ int ring_code[kRingEnt];
     __shared__ int2 ring_rowlen[kRingSlot];
@@ -147,16 +147,27 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
         const int n_ent = (int)(a.tile_ent0[t + 1] - ent0);
         const int64_t ext0 = a.tile_ext0[t];
         const int n_ext = (int)(a.tile_ext0[t + 1] - ext0);
-        for (int e = threadIdx.x; e < n_ext; e += 256) opnd[kMaxB + e] = kSentinel;
+        for (int e = threadIdx.x; e < n_ext; e += 256) opnd[a.B + e] = kSentinel;
         __syncthreads();
 
-        const long long t_start = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+        const long long t_start = a.dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
         long long w_load = 0, w_ext = 0;
         if (wave == 0) {
             // ---- compute wave: one lane per row of the step, CRS-order fma chain ----
+            // Per step the dependent chain is: operand read (LDS) -> fma chain -> division -> result write
+            // (LDS).  Everything else is taken off it: the step's codes / values / b / D are read from the
+            // rings while the PREVIOUS step divides (they do not depend on its result), the loaders'
+            // watermarks are re-read only when the cached copy does not cover the step, and the wave's own
+            // progress is published every 8 steps.
             int2 d_cur = a.step_desc[sd0 + min(lane, n_steps)];
             int2 d_nxt = a.step_desc[sd0 + min(lane + 1, n_steps)];
             int2 p_cur = d_cur, p_nxt = d_nxt; // the following batch of 64 step descriptors, fetched a batch ahead
+            int ent_loaded = 0, slot_loaded = 0; // cached watermarks of the loaders
+            bool have = false;                   // the ring reads of the coming step are already in flight
+            int2 rl = make_int2(0, 0);
+            double2 bd = make_double2(0.0, 1.0);
+            int code[4] = {0, 0, 0, 0};
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
             for (int s = 0; s < n_steps; ++s) {
                 const int j = s & 63;
                 if (j == 0) {
@@ -164,40 +175,56 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     p_cur = a.step_desc[sd0 + min(s + 64 + lane, n_steps)];
                     p_nxt = a.step_desc[sd0 + min(s + 65 + lane, n_steps)];
                 }
-                const int slot_b = __builtin_amdgcn_readlane(d_cur.x, j), ent_b = __builtin_amdgcn_readlane(d_cur.y, j);
-                const int slot_e = __builtin_amdgcn_readlane(d_nxt.x, j), ent_e = __builtin_amdgcn_readlane(d_nxt.y, j);
+                const int dx = __builtin_amdgcn_readlane(d_cur.x, j), ent_b = __builtin_amdgcn_readlane(d_cur.y, j);
+                const int dxe = __builtin_amdgcn_readlane(d_nxt.x, j), ent_e = __builtin_amdgcn_readlane(d_nxt.y, j);
+                const int slot_b = dx & 0xffff, L = dx >> 16, slot_e = dxe & 0xffff;
                 const int w = slot_e - slot_b;
-                const int L = w > 0 ? (ent_e - ent_b) / w : 0;
-                // the loaders have to be past this step
-                unsigned spins = 0;
-                const long long t0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-                while ((int)lds_acquire(&ctl[C_ENT_LOADED]) < ent_e || (int)lds_acquire(&ctl[C_SLOT_LOADED]) < slot_e) {
-                    if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (a.dbg) w_load += (long long)__builtin_readcyclecounter() - t0;
                 const bool active = lane < w;
-                const int sl = (slot_b + lane) & (kRingSlot - 1);
-                const int2 rl = active ? ring_rowlen[sl] : make_int2(0, 0);
-                const double2 bd = active ? ring_bD[sl] : make_double2(0.0, 1.0);
+                if (!have) {
+                    // the loaders have to be past this step
+                    unsigned spins = 0;
+                    const long long t0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+                    if (ent_loaded < ent_e || slot_loaded < slot_e) { // about to wait: the loaders must know how far the rings are free
+                        if (lane == 0) { lds_release(&ctl[C_ENT_DONE], (unsigned)ent_b); lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_b); }
+                    }
+                    while (ent_loaded < ent_e || slot_loaded < slot_e) {
+                        ent_loaded = (int)lds_acquire(&ctl[C_ENT_LOADED]);
+                        slot_loaded = (int)lds_acquire(&ctl[C_SLOT_LOADED]);
+                        if (ent_loaded >= ent_e && slot_loaded >= slot_e) break;
+                        if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (a.dbg) w_load += (long long)__builtin_readcyclecounter() - t0;
+                    const int sl = (slot_b + lane) & (kRingSlot - 1);
+                    rl = active ? ring_rowlen[sl] : make_int2(0, 0);
+                    bd = active ? ring_bD[sl] : make_double2(0.0, 1.0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int idx = (ent_b + q * w + lane) & (kRingEnt - 1);
+                        code[q] = active && q < L ? ring_code[idx] : 0;
+                        v[q] = active && q < L ? ring_val[idx] : 0.0;
+                    }
+                }
+                have = false;
                 double acc = 0.0;
                 bool lost = false;
-                // rounds of 4 entries: their codes and values, then their operands, are read together; the fma
-                // chain then runs in CRS order
+                // rounds of 4 entries: their operands are read together; the fma chain then runs in CRS order
                 for (int k0 = 0; k0 < L; k0 += 4) {
-                    int code[4];
-                    double v[4];
                     unsigned long long bits[4];
+                    if (k0 > 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int idx = (ent_b + (k0 + q) * w + lane) & (kRingEnt - 1);
+                            code[q] = active && k0 + q < L ? ring_code[idx] : 0;
+                            v[q] = active && k0 + q < L ? ring_val[idx] : 0.0;
+                        }
+                    }
                     bool on[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         on[q] = active && k0 + q < rl.y;
-                        const int idx = (ent_b + (k0 + q) * w + lane) & (kRingEnt - 1);
-                        code[q] = on[q] ? ring_code[idx] : 0;
-                        v[q] = on[q] ? ring_val[idx] : 0.0;
+                        bits[q] = __hip_atomic_load(&opnd[code[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bits[q] = __hip_atomic_load(&opnd[code[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     // wait (whole wave, LDS only) until the poller has delivered the external operands of this round
                     unsigned sp2 = 0;
                     const long long t1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -218,20 +245,47 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     for (int q = 0; q < 4; ++q)
                         if (on[q]) acc = fma(v[q], __longlong_as_double((long long)bits[q]), acc);
                 }
-                const double res = (bd.x - acc) / bd.y;
+                const double num = bd.x - acc, den = bd.y;
+                const int row = rl.x;
+                // ring reads of the next step, issued before the division of this one (same descriptor batch, and
+                // the cached watermarks already cover it; otherwise the next trip does it the slow way)
+                if (j < 63 && s + 1 < n_steps) {
+                    const int n_dx = __builtin_amdgcn_readlane(d_cur.x, j + 1), n_ent_b = ent_e;
+                    const int n_dxe = __builtin_amdgcn_readlane(d_nxt.x, j + 1), n_ent_e = __builtin_amdgcn_readlane(d_nxt.y, j + 1);
+                    const int n_slot_b = n_dx & 0xffff, n_L = n_dx >> 16, n_slot_e = n_dxe & 0xffff;
+                    if (ent_loaded >= n_ent_e && slot_loaded >= n_slot_e) {
+                        const int n_w = n_slot_e - n_slot_b;
+                        const bool n_active = lane < n_w;
+                        const int sl = (n_slot_b + lane) & (kRingSlot - 1);
+                        rl = n_active ? ring_rowlen[sl] : make_int2(0, 0);
+                        bd = n_active ? ring_bD[sl] : make_double2(0.0, 1.0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int idx = (n_ent_b + q * n_w + lane) & (kRingEnt - 1);
+                            code[q] = n_active && q < n_L ? ring_code[idx] : 0;
+                            v[q] = n_active && q < n_L ? ring_val[idx] : 0.0;
+                        }
+                        have = true;
+                    }
+                }
+                const double res = num / den;
                 unsigned long long out = (unsigned long long)__double_as_longlong(res);
                 if (res != res || lost) out = kCanonNaN; // never publish the sentinel pattern
                 if (lost && lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (active) {
                     __hip_atomic_store(&opnd[slot_b + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    a.x[rl.x] = __longlong_as_double((long long)out);
+                    a.x[row] = __longlong_as_double((long long)out);
                     __hip_atomic_store(&a.xs[slot0 + slot_b + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (lane == 0) { lds_release(&ctl[C_ENT_DONE], (unsigned)ent_e); lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_e); }
+                if (lane == 0 && ((s & 7) == 7 || s + 1 == n_steps)) {
+                    // what the rings may overwrite: everything before this step's successor (its reads may be in flight)
+                    lds_release(&ctl[C_ENT_DONE], (unsigned)ent_b);
+                    lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_b);
+                }
             }
             if (a.dbg && lane == 0) {
                 long long *d = a.dbg + (int64_t)t * 8;
-                d[0] = t_start; d[1] = (long long)__builtin_readcyclecounter(); d[2] = w_load; d[3] = w_ext; d[7] = n_steps;
+                d[0] = t_start; d[1] = (long long)__builtin_amdgcn_s_memrealtime(); d[2] = w_load; d[3] = w_ext; d[7] = n_steps;
             }
         } else if (wave == 1) {
             // ---- entry loader: the tile's entry stream (step order, k-major / lane-minor) into the ring ----
@@ -262,7 +316,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 done += chunk;
                 lds_release(&ctl[C_ENT_LOADED], (unsigned)done);
             }
-            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 4] = (long long)__builtin_readcyclecounter();
+            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 4] = (long long)__builtin_amdgcn_s_memrealtime();
         } else if (wave == 2) {
             // ---- per-row operand loader: row index, row length, b[row], D[row] in slot order ----
             constexpr int U = kSlotChunk / 64;
@@ -299,7 +353,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 done += chunk;
                 lds_release(&ctl[C_SLOT_LOADED], (unsigned)done);
             }
-            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 5] = (long long)__builtin_readcyclecounter();
+            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
         } else {
             // ---- poller: external operands in first-need order; every lane advances on its own ----
             int e = lane;
@@ -312,7 +366,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     const bool give_up = ++spins > kSpinMem;
                     if (vbits != kSentinel || give_up) {
                         if (give_up) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(&opnd[kMaxB + e], give_up && vbits == kSentinel ? kCanonNaN : vbits, __ATOMIC_RELAXED,
+                        __hip_atomic_store(&opnd[a.B + e], give_up && vbits == kSentinel ? kCanonNaN : vbits, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                         e += 64;
                         src = src_next;
@@ -322,7 +376,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 6] = (long long)__builtin_readcyclecounter();
+            if (a.dbg && lane == 0) a.dbg[(int64_t)t * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
         }
         __syncthreads();
     }
@@ -408,7 +462,7 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                         L = L2;
                         ++w;
                     }
-                    step_desc.push_back(make_int2(s, (int)((int64_t)ent_code.size() - tile_ent0[t])));
+                    step_desc.push_back(make_int2(s | (L << 16), (int)((int64_t)ent_code.size() - tile_ent0[t])));
                     for (int k = 0; k < L; ++k)
                         for (int i = 0; i < w; ++i) {
                             const int2 rl = slot_rowlen[(size_t)(p0 + s + i)];
@@ -425,14 +479,14 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                                     ext_ord[(size_t)gs] = n_ext_tile++;
                                     ext_src.push_back(gs);
                                 }
-                                ent_code.push_back(kMaxB + ext_ord[(size_t)gs]);
+                                ent_code.push_back(B + ext_ord[(size_t)gs]);
                             }
                         }
                     s += w;
                 }
             }
             step_desc.push_back(make_int2(m, (int)((int64_t)ent_code.size() - tile_ent0[t]))); // end marker
-            if (n_ext_tile > kMaxExt) too_many_ext = true;
+            if (n_ext_tile > kOpnd - B) too_many_ext = true;
         }
         if (too_many_ext) continue; // halve the tile
         tile_step0[n_tiles] = (int64_t)step_desc.size();

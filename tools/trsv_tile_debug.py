@@ -20,16 +20,16 @@ for _ in range(2):
     ctx.sptrsv(Ls, x, D, b); ctx.sync()
 d = np.fromfile(F, dtype=np.int64).reshape(-1, 8)
 t0 = d[:, 0].min()
-f = 100.0  # s_memtime ticks per us (100 MHz constant clock)
+f = 100.0  # s_memrealtime ticks per us (100 MHz); the wait counters are core cycles (~2400 per us)
 start, end = (d[:, 0] - t0) / f, (d[:, 1] - t0) / f
 print(f"tiles {len(d)}  sweep {end.max():.1f} us (first start -> last end)")
 dur = end - start
 print(f"tile duration us: mean {dur.mean():.1f} median {np.median(dur):.1f} max {dur.max():.1f}; steps/tile mean {d[:,7].mean():.1f}")
-print(f"compute wave waited for loaders: mean {d[:,2].mean()/f:.1f} us/tile; for external operands: mean {d[:,3].mean()/f:.1f} us/tile")
+print(f"compute wave waited for loaders: mean {d[:,2].mean()/2400:.1f} us/tile; for external operands: mean {d[:,3].mean()/2400:.1f} us/tile")
 for nm, c in (("entry loader", 4), ("slot loader", 5), ("poller", 6)):
     print(f"{nm} finished after (from tile start) mean {((d[:,c]-d[:,0])/f).mean():.1f} us")
 k = np.arange(len(d))
 for i in (0, 1, 2, 3, len(d)//2, len(d)//2+1, len(d)-1):
-    print(f"tile {i}: start {start[i]:.1f} end {end[i]:.1f} wait_load {d[i,2]/f:.1f} wait_ext {d[i,3]/f:.1f}")
+    print(f"tile {i}: start {start[i]:.1f} end {end[i]:.1f} wait_load {d[i,2]/2400:.1f} wait_ext {d[i,3]/2400:.1f}")
 conc = [(np.sum((start <= t) & (end > t))) for t in np.linspace(0, end.max(), 21)[1:-1]]
 print("tiles in flight at 5%..95% of the sweep:", conc)
