@@ -37,9 +37,9 @@ struct bis_trsv_tiled {
     int64_t n_steps = 0, n_quads = 0, n_ext = 0;
     // device arrays.  "slot" = position of a row in (tile, local level, processing order) order.
     int32_t *slot_row = nullptr;    // [n]  slot -> row
-    int2 *step_desc = nullptr;      // per tile, per step: {first slot | quads per row << 16, first quad}, relative to the tile, + an end marker
+    int4 *step_desc = nullptr;      // per tile, per step: {first slot, rows | quads per row << 8, first quad, external ordinals first needed up to and incl. this step}, relative to the tile
     int64_t *tile_slot0 = nullptr;  // [n_tiles + 1]
-    int64_t *tile_step0 = nullptr;  // [n_tiles + 1] index into step_desc (incl. one end marker per tile)
+    int64_t *tile_step0 = nullptr;  // [n_tiles + 1] index into step_desc
     int64_t *tile_quad0 = nullptr;  // [n_tiles + 1]
     int64_t *tile_ext0 = nullptr;   // [n_tiles + 1]
     int4 *quad_code = nullptr;      // [n_quads] 4 consecutive entries of one row: operand indices into the tile's LDS operand array
@@ -61,9 +61,13 @@ namespace {
 
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload (same as bis_sptrsv.hip)
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
-constexpr int kMaxB = 2048;       // rows per tile at most
-constexpr int kOpnd = 4096;       // LDS operand array (32 KiB): the tile's own results, its distinct external operands, one zero
-constexpr int kZeroSlot = kOpnd - 1; // operand of padding entries: 0.0, so fma(0, 0, acc) leaves acc as it is
+constexpr int kMaxB = 32768;      // rows per tile at most
+constexpr int kOwn = 2048;        // LDS ring of the tile's own results (16 KiB), by slot: an in-tile operand must have been produced
+                                  // fewer than kOwn - 64 slots before its consumer, else it is fetched like an external one
+constexpr int kExt = 2048;        // LDS ring of external operands (16 KiB), by ordinal (first-need order)
+constexpr int kExtWindow = 512;   // an ordinal may be used again while it is among the last kExtWindow ones first needed
+constexpr int kZeroSlot = kOwn + kExt; // operand of padding entries: 0.0, so fma(0, 0, acc) leaves acc as it is
+constexpr int kOpnd = kOwn + kExt + 2;
 constexpr int kRingQ = 512;       // quad ring (LDS: 8 + 16 KiB)
 constexpr int kRingSlot = 256;    // per-row operand ring (LDS: 1 + 4 KiB)
 constexpr int kQuadChunk = 256;   // quads per loader round (4 per lane)
@@ -71,7 +75,7 @@ constexpr int kSlotChunk = 128;   // rows per loader round (2 per lane)
 constexpr unsigned kSpinLds = 1u << 24;  // polls of an LDS word before a wave gives up (seconds)
 constexpr unsigned kSpinMem = 1u << 22;  // polls of a memory word
 
-enum { C_TICKET = 0, C_Q_LOADED, C_Q_DONE, C_SLOT_LOADED, C_SLOT_DONE, C_N = 8 };
+enum { C_TICKET = 0, C_Q_LOADED, C_Q_DONE, C_SLOT_LOADED, C_SLOT_DONE, C_EXT_WM, C_EXT_SAFE, C_N = 8 };
 
 // Hand-offs between the waves of one workgroup go through LDS words.  The LDS executes one wave's
 // operations in issue order, so "data writes, then the watermark write" needs no wait in between, and a
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void gather_entries_kernel(const double *__res
 
 struct TiledArgs {
     const int32_t *slot_row;
-    const int2 *step_desc;
+    const int4 *step_desc;
     const int64_t *tile_slot0, *tile_step0, *tile_quad0, *tile_ext0;
     const int4 *quad_code;
     const double2 *quad_val;
@@ -124,11 +128,17 @@ struct TiledArgs {
                     // loaders / for external operands, end of the quad loader / slot loader / poller, steps
 };
 
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 template <bool DBG>
 __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
-    // operands of the tile's rows: [0, rows) results of the tile itself, by slot; then its distinct external operands, by
-    // ordinal (sentinel until the poller delivers them); last the zero slot.  The entry codes index this array directly:
-    // one LDS read per operand, no branch on where it comes from.
+    // operands of the tile's rows, indexed directly by the entry codes (one LDS read per operand, no branch on where it
+    // comes from): [0, kOwn) ring of the tile's own results by slot, [kOwn, kOwn + kExt) ring of the external operands
+    // by ordinal, then the zero slot.
     __shared__ unsigned long long opnd[kOpnd];
     __shared__ int4 ring_code[kRingQ];
     __shared__ double2 ring_val[2 * kRingQ];
@@ -139,47 +149,48 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
     if (threadIdx.x == 0) opnd[kZeroSlot] = 0ull;
     for (;;) {
         if (threadIdx.x == 0) ctl[C_TICKET] = atomicAdd(a.ticket, 1u);
-        if (threadIdx.x >= 1 && threadIdx.x < C_N) ctl[threadIdx.x] = 0u;
+        if (threadIdx.x >= 1 && threadIdx.x < C_N) ctl[threadIdx.x] = threadIdx.x == C_EXT_SAFE ? (unsigned)(-kExtWindow) : 0u;
         __syncthreads();
         const int t = (int)ctl[C_TICKET];
         if (t >= a.n_tiles) return; // every wave reaches this once the tickets run out
         const int64_t slot0 = a.tile_slot0[t];
         const int n_slots = (int)(a.tile_slot0[t + 1] - slot0);
         const int64_t sd0 = a.tile_step0[t];
-        const int n_steps = (int)(a.tile_step0[t + 1] - sd0) - 1;
+        const int n_steps = (int)(a.tile_step0[t + 1] - sd0);
         const int64_t quad0 = a.tile_quad0[t];
         const int n_quads = (int)(a.tile_quad0[t + 1] - quad0);
         const int64_t ext0 = a.tile_ext0[t];
         const int n_ext = (int)(a.tile_ext0[t + 1] - ext0);
-        for (int e = threadIdx.x; e < n_ext; e += 256) opnd[n_slots + e] = kSentinel;
-        __syncthreads();
         const long long t_start = DBG ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
         long long w_load = 0, w_ext = 0;
 
         if (wave == 0) {
-            // ---- compute wave: one lane per row of the step, CRS-order fma chain.  Few lanes are busy (as many as the
-            // tile has independent rows at a time), so what counts is the number of wave instructions per step: no
-            // predication (lanes beyond the step's rows read valid LDS and are masked at the stores only), padding
-            // entries multiply 0 by the zero slot, the loaders' watermarks are re-read only when the cached copy does
-            // not cover the step, the wave's own progress is published every 8 steps.
-            int2 d_cur = a.step_desc[sd0 + min(lane, n_steps)];
-            int2 d_nxt = a.step_desc[sd0 + min(lane + 1, n_steps)];
-            int2 p_cur = d_cur, p_nxt = d_nxt; // the following batch of 64 step descriptors, fetched a batch ahead
-            int q_loaded = 0, slot_loaded = 0; // cached watermarks of the loaders
+            // ---- compute wave: one lane per row of the step, CRS-order fma chain.  What counts is the number of wave
+            // instructions per step: no predication (lanes beyond the step's rows read valid LDS and are masked at the
+            // stores only), padding entries multiply 0 by the zero slot, readiness is three watermarks (the two loaders',
+            // the poller's) cached in registers and re-read only when they do not cover the step, the wave's own progress
+            // is published every 8 steps.
+            int4 d_cur = a.step_desc[sd0 + min(lane, n_steps - 1)];
+            int4 p_cur = d_cur; // the following batch of 64 step descriptors, fetched a batch ahead
+            int q_loaded = 0, slot_loaded = 0, ext_wm = 0; // cached watermarks
+            int ext_prev = 0;
             for (int s = 0; s < n_steps; ++s) {
                 const int j = s & 63;
                 if (j == 0) {
-                    if (s > 0) { d_cur = p_cur; d_nxt = p_nxt; }
-                    p_cur = a.step_desc[sd0 + min(s + 64 + lane, n_steps)];
-                    p_nxt = a.step_desc[sd0 + min(s + 65 + lane, n_steps)];
+                    if (s > 0) d_cur = p_cur;
+                    p_cur = a.step_desc[sd0 + min(s + 64 + lane, n_steps - 1)];
                 }
-                const int dx = __builtin_amdgcn_readlane(d_cur.x, j), quad_b = __builtin_amdgcn_readlane(d_cur.y, j);
-                const int dxe = __builtin_amdgcn_readlane(d_nxt.x, j), quad_e = __builtin_amdgcn_readlane(d_nxt.y, j);
-                const int slot_b = dx & 0xffff, nq = dx >> 16, slot_e = dxe & 0xffff;
-                const int w = slot_e - slot_b;
-                if (q_loaded < quad_e || slot_loaded < slot_e) {
-                    // about to wait for the loaders: tell them how far the rings are free
-                    if (lane == 0) { lds_release(&ctl[C_Q_DONE], (unsigned)quad_b); lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_b); }
+                const int slot_b = __builtin_amdgcn_readlane(d_cur.x, j), wn = __builtin_amdgcn_readlane(d_cur.y, j);
+                const int quad_b = __builtin_amdgcn_readlane(d_cur.z, j), ext_end = __builtin_amdgcn_readlane(d_cur.w, j);
+                const int w = wn & 0xff, nq = wn >> 8;
+                const int slot_e = slot_b + w, quad_e = quad_b + w * nq;
+                if (q_loaded < quad_e || slot_loaded < slot_e || ext_wm < ext_end) {
+                    // about to wait: tell the loaders and the poller how far their rings are free
+                    if (lane == 0) {
+                        lds_release(&ctl[C_Q_DONE], (unsigned)quad_b);
+                        lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_b);
+                        lds_release(&ctl[C_EXT_SAFE], (unsigned)(ext_prev - kExtWindow));
+                    }
                     unsigned spins = 0;
                     const long long t0 = DBG ? (long long)__builtin_readcyclecounter() : 0;
                     for (;;) {
@@ -189,30 +200,25 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                         if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    if (DBG) w_load += (long long)__builtin_readcyclecounter() - t0;
+                    const long long t1 = DBG ? (long long)__builtin_readcyclecounter() : 0;
+                    if (DBG) w_load += t1 - t0;
+                    for (;;) {
+                        ext_wm = (int)lds_acquire(&ctl[C_EXT_WM]);
+                        if (ext_wm >= ext_end) break;
+                        if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (DBG) w_ext += (long long)__builtin_readcyclecounter() - t1;
                 }
-                const bool active = lane < w;
                 const int sl = (slot_b + lane) & (kRingSlot - 1);
                 const int row = ring_row[sl];
                 const double2 bd = ring_bD[sl];
                 double acc = 0.0;
-                bool lost = false;
                 int qi = quad_b + lane;
                 for (int g = 0; g < nq; ++g, qi += w) {
                     const int4 c = ring_code[qi & (kRingQ - 1)];
                     const double2 v01 = ring_val[2 * (qi & (kRingQ - 1))], v23 = ring_val[2 * (qi & (kRingQ - 1)) + 1];
-                    unsigned long long x0 = lds_word(&opnd[c.x]), x1 = lds_word(&opnd[c.y]), x2 = lds_word(&opnd[c.z]), x3 = lds_word(&opnd[c.w]);
-                    // external operands the poller has not delivered yet: the whole wave waits (LDS polls only)
-                    if (__ballot(active && (x0 == kSentinel || x1 == kSentinel || x2 == kSentinel || x3 == kSentinel))) {
-                        unsigned sp2 = 0;
-                        const long long t1 = DBG ? (long long)__builtin_readcyclecounter() : 0;
-                        do {
-                            __builtin_amdgcn_s_sleep(1);
-                            x0 = lds_word(&opnd[c.x]); x1 = lds_word(&opnd[c.y]); x2 = lds_word(&opnd[c.z]); x3 = lds_word(&opnd[c.w]);
-                            if (++sp2 > kSpinLds) { lost = true; break; }
-                        } while (__ballot(active && (x0 == kSentinel || x1 == kSentinel || x2 == kSentinel || x3 == kSentinel)));
-                        if (DBG) w_ext += (long long)__builtin_readcyclecounter() - t1;
-                    }
+                    const unsigned long long x0 = lds_word(&opnd[c.x]), x1 = lds_word(&opnd[c.y]), x2 = lds_word(&opnd[c.z]), x3 = lds_word(&opnd[c.w]);
                     acc = fma(v01.x, __longlong_as_double((long long)x0), acc);
                     acc = fma(v01.y, __longlong_as_double((long long)x1), acc);
                     acc = fma(v23.x, __longlong_as_double((long long)x2), acc);
@@ -220,14 +226,18 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 }
                 const double res = (bd.x - acc) / bd.y;
                 unsigned long long out = (unsigned long long)__double_as_longlong(res);
-                if (res != res || lost) out = kCanonNaN; // never publish the sentinel pattern
-                if (lost && lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (active) {
-                    __hip_atomic_store(&opnd[slot_b + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (res != res) out = kCanonNaN; // never publish the sentinel pattern
+                if (lane < w) {
+                    __hip_atomic_store(&opnd[(slot_b + lane) & (kOwn - 1)], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     a.x[row] = __longlong_as_double((long long)out);
                     __hip_atomic_store(&a.xs[slot0 + slot_b + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (lane == 0 && (s & 7) == 7) { lds_release(&ctl[C_Q_DONE], (unsigned)quad_b); lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_b); }
+                if (lane == 0 && (s & 7) == 7) {
+                    lds_release(&ctl[C_Q_DONE], (unsigned)quad_b);
+                    lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_b);
+                    lds_release(&ctl[C_EXT_SAFE], (unsigned)(ext_prev - kExtWindow));
+                }
+                ext_prev = ext_end;
             }
             if (DBG && lane == 0) {
                 long long *d = a.dbg + (int64_t)t * 8;
@@ -304,18 +314,21 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             }
             if (DBG && lane == 0) a.dbg[(int64_t)t * 8 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
         } else {
-            // ---- poller: external operands in first-need order; every lane advances on its own ----
+            // ---- poller: external operands in first-need order into their ring; every lane advances on its own, the
+            // watermark (all ordinals below it delivered) is the minimum over the lanes ----
             int e = lane;
             int src = e < n_ext ? a.ext_src[ext0 + e] : 0;
             int src_next = e + 64 < n_ext ? a.ext_src[ext0 + e + 64] : 0;
             unsigned spins = 0;
+            int wm_pub = 0;
             while (__ballot(e < n_ext)) {
-                if (e < n_ext) {
+                const int safe = (int)lds_acquire(&ctl[C_EXT_SAFE]); // ordinals below it are dead: their ring positions may be reused
+                if (e < n_ext && e < safe + kExt) {
                     const unsigned long long vbits = __hip_atomic_load(&a.xs[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool give_up = ++spins > kSpinMem;
                     if (vbits != kSentinel || give_up) {
                         if (give_up) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(&opnd[n_slots + e], give_up && vbits == kSentinel ? kCanonNaN : vbits, __ATOMIC_RELAXED,
+                        __hip_atomic_store(&opnd[kOwn + (e & (kExt - 1))], give_up && vbits == kSentinel ? kCanonNaN : vbits, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                         e += 64;
                         src = src_next;
@@ -323,8 +336,11 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                         spins = 0;
                     }
                 }
+                const int wm = min(wave_min_int(e), n_ext);
+                if (wm != wm_pub) { wm_pub = wm; if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)wm); }
                 __builtin_amdgcn_s_sleep(1);
             }
+            if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)n_ext);
             if (DBG && lane == 0) a.dbg[(int64_t)t * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
         }
         __syncthreads();
@@ -333,11 +349,11 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
 
 } // namespace
 
-// ---- plan (host analysis, version 1) --------------------------------------------------------------
+// ---- plan (host analysis) ---------------------------------------------------------------------------
 // Input: the strictly triangular pattern on the host.  Processing order: ascending rows (forward) or
 // descending rows (backward) -- the reference's substitution order, always a linear extension.
-// Tiles: intervals of the processing order, grown greedily until they hold kMaxB rows or their rows plus
-// their distinct external operands fill the LDS operand array.
+// Tiles: intervals of the processing order of up to max_rows rows, cut where the next tile's first row
+// reaches back farthest.
 bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_tiled **out) {
     *out = nullptr;
     const int64_t n = T->n_rows;
@@ -351,12 +367,11 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     int max_len = 0;
     for (int64_t r = 0; r < n; ++r) max_len = std::max<int>(max_len, (int)(rp[r + 1] - rp[r]));
     if ((max_len + 3) / 4 > kRingQ / 2) return BIS_OK; // a single row must fit half the quad ring
-    const int max_rows = bis_opts().trsv_tile_rows > 0 ? std::min(bis_opts().trsv_tile_rows, kMaxB) : kMaxB;
-    // pass A: tile boundaries.  A tile may grow until it holds max_rows rows or its rows plus its distinct external
-    // operands fill the operand array; within the second half of that extent it is cut where the next tile's first
+    const int max_rows = bis_opts().trsv_tile_rows > 0 ? std::min(bis_opts().trsv_tile_rows, kMaxB) : 16384;
+    // pass A: tile boundaries.  Within the second half of its allowed extent a tile is cut where the next tile's first
     // row reaches back farthest (gap = distance to its nearest dependency).  Cutting just after a row the next row
     // depends on -- the middle of a grid line -- would make every tile wait for the END of its predecessor and
-    // serialise the sweep (measured: 494 ms instead of 6 ms on the 256^3 7-point grid); cutting at the start of a
+    // serialise the sweep (measured: 494 ms instead of 4 ms on the 256^3 7-point grid); cutting at the start of a
     // grid line lets it start on the predecessor's early results.
     std::vector<int64_t> tile_pos0{0};
     {
@@ -367,25 +382,9 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
             for (int64_t k = rp[r]; k < rp[r + 1]; ++k) nearest = std::max(nearest, pos_of(col[k]));
             gap[(size_t)p] = (int32_t)std::min<int64_t>(p - nearest, INT32_MAX); // no dependency: p + 1
         }
-        std::vector<int64_t> stamp((size_t)n, -1); // per position: start of the tile that counted it last as external
         for (int64_t p0 = 0; p0 < n;) {
-            int rows = 0, ext = 0;
-            int64_t p = p0;
-            for (; p < n && rows < max_rows; ++p) {
-                const int64_t r = row_at(p);
-                int new_ext = 0;
-                for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
-                    const int64_t q = pos_of(col[k]);
-                    if (q < p0 && stamp[(size_t)q] != p0) { stamp[(size_t)q] = p0; ++new_ext; }
-                }
-                if (rows + 1 + ext + new_ext > kOpnd - 1) {
-                    if (rows == 0) return BIS_OK; // one row alone does not fit
-                    break;
-                }
-                ++rows;
-                ext += new_ext;
-            }
-            int64_t cut = p; // [p0, p) fits
+            const int64_t p = std::min<int64_t>(n, p0 + max_rows);
+            int64_t cut = p;
             if (p < n) {
                 int32_t best = -1;
                 for (int64_t c = p0 + std::max<int64_t>(1, (p - p0) / 2); c <= p; ++c)
@@ -396,19 +395,19 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
         }
     }
     const int64_t n_tiles = (int64_t)tile_pos0.size() - 1;
-    if (n_tiles > INT32_MAX || n / n_tiles < 64) return BIS_OK; // tiles too small to pay: keep the level-scheduled sweep
+    if (n_tiles > INT32_MAX) return BIS_OK;
     std::vector<int32_t> tile_of((size_t)n);
     for (int64_t t = 0; t < n_tiles; ++t)
         for (int64_t p = tile_pos0[t]; p < tile_pos0[t + 1]; ++p) tile_of[(size_t)p] = (int32_t)t;
     // pass B: local levels, steps, quads, external ordinals
     std::vector<int32_t> slot_row((size_t)n);
-    std::vector<int2> step_desc;
+    std::vector<int4> step_desc;
     std::vector<int64_t> tile_step0(n_tiles + 1, 0), tile_quad0(n_tiles + 1, 0), tile_ext0(n_tiles + 1, 0);
     std::vector<int4> quad_code;
     std::vector<int64_t> quad_src; // CRS index of each entry (4 per quad), -1 = padding
     std::vector<int32_t> ext_src;
     std::vector<int32_t> lidx((size_t)n); // row -> slot within its tile
-    step_desc.reserve((size_t)(n / 4));
+    step_desc.reserve((size_t)(n / 16));
     quad_code.reserve((size_t)(T->nnz / 3));
     quad_src.reserve((size_t)(T->nnz / 3) * 4);
     std::vector<int> lvl(kMaxB), order(kMaxB), cnt;
@@ -457,7 +456,8 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                     nq = nq2;
                     ++w;
                 }
-                step_desc.push_back(make_int2(s | (nq << 16), (int)((int64_t)quad_code.size() - tile_quad0[t])));
+                const int quad_b = (int)((int64_t)quad_code.size() - tile_quad0[t]);
+                const int ext_base = n_ext_tile; // ordinals first needed before this step
                 for (int g = 0; g < nq; ++g)
                     for (int i = 0; i < w; ++i) {
                         const int64_t r = slot_row[(size_t)(p0 + s + i)];
@@ -467,25 +467,25 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                             if (kk >= rp[r + 1]) { code[q] = kZeroSlot; quad_src.push_back(-1); continue; }
                             quad_src.push_back(kk);
                             const int64_t qp = pos_of(col[kk]);
-                            if (qp >= p0) {
-                                code[q] = lidx[(size_t)col[kk]];
-                            } else {
-                                const int32_t gs = (int32_t)(tile_pos0[tile_of[(size_t)qp]] + lidx[(size_t)col[kk]]);
-                                if (ext_stamp[(size_t)gs] != (int32_t)t) { // first need in this tile: next ordinal
-                                    ext_stamp[(size_t)gs] = (int32_t)t;
+                            const int ps = lidx[(size_t)col[kk]]; // the operand's slot within ITS tile
+                            if (qp >= p0 && (s + i) - ps <= kOwn - 128) {
+                                code[q] = ps & (kOwn - 1); // still in the ring of the tile's own results
+                            } else { // another tile's result, or one of this tile's that has left the ring: through the poller
+                                const int32_t gs = (int32_t)(tile_pos0[tile_of[(size_t)qp]] + ps);
+                                if (ext_stamp[(size_t)gs] != (int32_t)t || ext_ord[(size_t)gs] < ext_base - kExtWindow) {
+                                    ext_stamp[(size_t)gs] = (int32_t)t; // first need, or last listed too long ago: next ordinal
                                     ext_ord[(size_t)gs] = n_ext_tile++;
                                     ext_src.push_back(gs);
                                 }
-                                code[q] = m + ext_ord[(size_t)gs];
+                                code[q] = kOwn + (ext_ord[(size_t)gs] & (kExt - 1));
                             }
                         }
                         quad_code.push_back(make_int4(code[0], code[1], code[2], code[3]));
                     }
+                step_desc.push_back(make_int4(s, w | (nq << 8), quad_b, n_ext_tile));
                 s += w;
             }
         }
-        step_desc.push_back(make_int2(m, (int)((int64_t)quad_code.size() - tile_quad0[t]))); // end marker
-        if (m + n_ext_tile > kOpnd - 1) { ctx->err = "tiled sptrsv plan: operand budget exceeded (internal)"; return BIS_ERR_INVALID; }
     }
     tile_step0[n_tiles] = (int64_t)step_desc.size();
     tile_quad0[n_tiles] = (int64_t)quad_code.size();
@@ -493,7 +493,7 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     // upload
     bis_trsv_tiled *p = new bis_trsv_tiled;
     p->n = n; p->n_tiles = (int)n_tiles; p->max_rows = tile_rows_max;
-    p->n_steps = (int64_t)step_desc.size() - n_tiles;
+    p->n_steps = (int64_t)step_desc.size();
     p->n_quads = (int64_t)quad_code.size();
     p->n_ext = (int64_t)ext_src.size();
     int64_t *d_src = nullptr;
@@ -504,7 +504,7 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
     };
     up((void **)&p->slot_row, slot_row.data(), 4 * slot_row.size());
-    up((void **)&p->step_desc, step_desc.data(), sizeof(int2) * step_desc.size());
+    up((void **)&p->step_desc, step_desc.data(), sizeof(int4) * step_desc.size());
     up((void **)&p->tile_slot0, tile_pos0.data(), 8 * tile_pos0.size());
     up((void **)&p->tile_step0, tile_step0.data(), 8 * tile_step0.size());
     up((void **)&p->tile_quad0, tile_quad0.data(), 8 * tile_quad0.size());
