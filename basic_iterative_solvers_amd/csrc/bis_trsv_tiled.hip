@@ -62,16 +62,17 @@ namespace {
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload (same as bis_sptrsv.hip)
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
 constexpr int kMaxB = 32768;      // rows per tile at most
-constexpr int kOwn = 2048;        // LDS ring of the tile's own results (16 KiB), by slot: an in-tile operand must have been produced
+constexpr int kOwn = 1024;        // LDS ring of the tile's own results (8 KiB), by slot: an in-tile operand must have been produced
                                   // fewer than kOwn - 64 slots before its consumer, else it is fetched like an external one
 constexpr int kExt = 2048;        // LDS ring of external operands (16 KiB), by ordinal (first-need order)
 constexpr int kExtWindow = 512;   // an ordinal may be used again while it is among the last kExtWindow ones first needed
 constexpr int kZeroSlot = kOwn + kExt; // operand of padding entries: 0.0, so fma(0, 0, acc) leaves acc as it is
 constexpr int kOpnd = kOwn + kExt + 2;
 constexpr int kRingQ = 512;       // quad ring (LDS: 8 + 16 KiB)
-constexpr int kRingSlot = 256;    // per-row operand ring (LDS: 1 + 4 KiB)
+constexpr int kRingSlot = 512;    // per-row operand ring (LDS: 2 + 8 KiB)
 constexpr int kQuadChunk = 256;   // quads per loader round (4 per lane)
-constexpr int kSlotChunk = 128;   // rows per loader round (2 per lane)
+constexpr int kSlotChunk = 256;   // rows per loader round (4 per lane)
+constexpr int kPollBlock = 512;   // external ordinals the poller has in flight (8 per lane); its watermark moves block by block
 constexpr unsigned kSpinLds = 1u << 24;  // polls of an LDS word before a wave gives up (seconds)
 constexpr unsigned kSpinMem = 1u << 22;  // polls of a memory word
 
@@ -244,19 +245,28 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 d[0] = t_start; d[1] = (long long)__builtin_amdgcn_s_memrealtime(); d[2] = w_load; d[3] = w_ext; d[7] = n_steps;
             }
         } else if (wave == 1) {
-            // ---- quad loader: the tile's entry stream (step order, quad-major / lane-minor) into the ring ----
+            // ---- quad loader: the tile's entry stream (step order, quad-major / lane-minor) into the ring; the next
+            // round's loads are in flight while this round waits for ring space and is written ----
             constexpr int U = kQuadChunk / 64;
+            int4 c_n[U];
+            double2 va_n[U], vb_n[U];
+            auto issue = [&](int done, int chunk) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t g = quad0 + done + min(u * 64 + lane, chunk - 1);
+                    c_n[u] = a.quad_code[g];
+                    va_n[u] = a.quad_val[2 * g];
+                    vb_n[u] = a.quad_val[2 * g + 1];
+                }
+            };
+            if (n_quads > 0) issue(0, min(kQuadChunk, n_quads));
             for (int done = 0; done < n_quads;) {
                 const int chunk = min(kQuadChunk, n_quads - done);
                 int4 c[U];
                 double2 va[U], vb[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int64_t g = quad0 + done + min(u * 64 + lane, chunk - 1);
-                    c[u] = a.quad_code[g];
-                    va[u] = a.quad_val[2 * g];
-                    vb[u] = a.quad_val[2 * g + 1];
-                }
+                for (int u = 0; u < U; ++u) { c[u] = c_n[u]; va[u] = va_n[u]; vb[u] = vb_n[u]; }
+                if (done + chunk < n_quads) issue(done + chunk, min(kQuadChunk, n_quads - done - chunk));
                 unsigned spins = 0;
                 while (done + chunk - (int)lds_acquire(&ctl[C_Q_DONE]) > kRingQ) {
                     if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
@@ -314,33 +324,47 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             }
             if (DBG && lane == 0) a.dbg[(int64_t)t * 8 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
         } else {
-            // ---- poller: external operands in first-need order into their ring; every lane advances on its own, the
-            // watermark (all ordinals below it delivered) is the minimum over the lanes ----
-            int e = lane;
-            int src = e < n_ext ? a.ext_src[ext0 + e] : 0;
-            int src_next = e + 64 < n_ext ? a.ext_src[ext0 + e + 64] : 0;
-            unsigned spins = 0;
-            int wm_pub = 0;
-            while (__ballot(e < n_ext)) {
-                const int safe = (int)lds_acquire(&ctl[C_EXT_SAFE]); // ordinals below it are dead: their ring positions may be reused
-                if (e < n_ext && e < safe + kExt) {
-                    const unsigned long long vbits = __hip_atomic_load(&a.xs[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool give_up = ++spins > kSpinMem;
-                    if (vbits != kSentinel || give_up) {
-                        if (give_up) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(&opnd[kOwn + (e & (kExt - 1))], give_up && vbits == kSentinel ? kCanonNaN : vbits, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                        e += 64;
-                        src = src_next;
-                        src_next = e + 64 < n_ext ? a.ext_src[ext0 + e + 64] : 0;
-                        spins = 0;
-                    }
+            // ---- poller: external operands in first-need order into their ring, a block of kPollBlock ordinals (8 per
+            // lane, all in flight together) at a time; the watermark (all ordinals below it delivered) moves when a
+            // block is complete ----
+            constexpr int U = kPollBlock / 64;
+            for (int base = 0; base < n_ext; base += kPollBlock) {
+                int src[U];
+                bool got[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = base + u * 64 + lane;
+                    got[u] = e >= n_ext;
+                    src[u] = got[u] ? 0 : a.ext_src[ext0 + e];
                 }
-                const int wm = min(wave_min_int(e), n_ext);
-                if (wm != wm_pub) { wm_pub = wm; if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)wm); }
-                __builtin_amdgcn_s_sleep(1);
+                // the ring positions of this block are free once the ordinals kExt before them are dead
+                unsigned spins = 0;
+                while (min(base + kPollBlock, n_ext) > (int)lds_acquire(&ctl[C_EXT_SAFE]) + kExt) {
+                    if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                spins = 0;
+                for (;;) {
+                    unsigned long long vb[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) vb[u] = got[u] ? 0ull : __hip_atomic_load(&a.xs[src[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool give_up = ++spins > kSpinMem;
+                    bool all = true;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (!got[u] && (vb[u] != kSentinel || give_up)) {
+                            __hip_atomic_store(&opnd[kOwn + ((base + u * 64 + lane) & (kExt - 1))], vb[u] == kSentinel ? kCanonNaN : vb[u],
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            got[u] = true;
+                        }
+                        all &= got[u];
+                    }
+                    if (give_up && lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (!__ballot(!all)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)min(base + kPollBlock, n_ext));
             }
-            if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)n_ext);
             if (DBG && lane == 0) a.dbg[(int64_t)t * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
         }
         __syncthreads();
