@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             // lane, all in flight together) at a time; the watermark (all ordinals below it delivered) moves when a
             // block is complete ----
             constexpr int U = kPollBlock / 64;
+            int wm_pub = 0;
             for (int base = 0; base < n_ext; base += kPollBlock) {
                 int src[U];
                 bool got[U];
@@ -360,10 +361,18 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                         all &= got[u];
                     }
                     if (give_up && lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // watermark = the first ordinal of the block not delivered yet (ordinals run lane-minor): a step may need
+                    // an early ordinal of this block to produce a later one of the same block
+                    int wm = min(base + kPollBlock, n_ext);
+#pragma unroll
+                    for (int u = U - 1; u >= 0; --u) {
+                        const unsigned long long open = __ballot(!got[u]);
+                        if (open) wm = base + u * 64 + (int)__builtin_ctzll(open);
+                    }
+                    if (wm != wm_pub) { wm_pub = wm; if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)wm); }
                     if (!__ballot(!all)) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)min(base + kPollBlock, n_ext));
             }
             if (DBG && lane == 0) a.dbg[(int64_t)t * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
         }
