@@ -72,7 +72,7 @@ constexpr int kRingQ = 512;       // quad ring (LDS: 8 + 16 KiB)
 constexpr int kRingSlot = 512;    // per-row operand ring (LDS: 2 + 8 KiB)
 constexpr int kQuadChunk = 256;   // quads per loader round (4 per lane)
 constexpr int kSlotChunk = 256;   // rows per loader round (4 per lane)
-constexpr int kPollBlock = 512;   // external ordinals the poller has in flight (8 per lane); its watermark moves block by block
+constexpr int kPollBlock = 128;   // external ordinals the poller has in flight (2 per lane); its watermark moves block by block
 constexpr unsigned kSpinLds = 1u << 24;  // polls of an LDS word before a wave gives up (seconds)
 constexpr unsigned kSpinMem = 1u << 22;  // polls of a memory word
 
@@ -402,26 +402,44 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     if ((max_len + 3) / 4 > kRingQ / 2) return BIS_OK; // a single row must fit half the quad ring
     const int max_rows = bis_opts().trsv_tile_rows > 0 ? std::min(bis_opts().trsv_tile_rows, kMaxB) : 16384;
     // pass A: tile boundaries.  Within the second half of its allowed extent a tile is cut where the next tile's first
-    // row reaches back farthest (gap = distance to its nearest dependency).  Cutting just after a row the next row
-    // depends on -- the middle of a grid line -- would make every tile wait for the END of its predecessor and
-    // serialise the sweep (measured: 494 ms instead of 4 ms on the 256^3 7-point grid); cutting at the start of a
-    // grid line lets it start on the predecessor's early results.
+    // row depends only on results its predecessor produces EARLY (small local level).  Cutting in the middle of a
+    // grid line would make every tile wait for the end of its predecessor and serialise the sweep (measured: 494 ms
+    // instead of 4 ms on the 256^3 7-point grid, 280 ms instead of 4 ms on the FEM-like input); cutting at the start
+    // of a grid line lets it start on the predecessor's early results.
     std::vector<int64_t> tile_pos0{0};
     {
-        std::vector<int32_t> gap((size_t)n);
-        for (int64_t p = 0; p < n; ++p) {
-            const int64_t r = row_at(p);
-            int64_t nearest = -1;
-            for (int64_t k = rp[r]; k < rp[r + 1]; ++k) nearest = std::max(nearest, pos_of(col[k]));
-            gap[(size_t)p] = (int32_t)std::min<int64_t>(p - nearest, INT32_MAX); // no dependency: p + 1
-        }
+        // score of a cut at position c of the candidate tile [p0, p): the local level, within that tile, of the deepest
+        // operand of row c (0 if all its operands precede the tile) -- how late in its predecessor the next tile could start
+        std::vector<int> lv((size_t)max_rows + 1);
         for (int64_t p0 = 0; p0 < n;) {
             const int64_t p = std::min<int64_t>(n, p0 + max_rows);
             int64_t cut = p;
             if (p < n) {
-                int32_t best = -1;
-                for (int64_t c = p0 + std::max<int64_t>(1, (p - p0) / 2); c <= p; ++c)
-                    if (gap[(size_t)c] >= best) { best = gap[(size_t)c]; cut = c; }
+                const int m = (int)(p - p0);
+                for (int i = 0; i < m; ++i) {
+                    const int64_t r = row_at(p0 + i);
+                    int l = 0;
+                    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+                        const int64_t q = pos_of(col[k]);
+                        if (q >= p0) l = std::max(l, lv[(size_t)(q - p0)] + 1);
+                    }
+                    lv[(size_t)i] = l;
+                }
+                {   // row p itself (the cut that keeps the whole extent)
+                    const int64_t r = row_at(p);
+                    int l = 0;
+                    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+                        const int64_t q = pos_of(col[k]);
+                        if (q >= p0) l = std::max(l, lv[(size_t)(q - p0)] + 1);
+                    }
+                    lv[(size_t)m] = l;
+                }
+                const int half = std::max(1, m / 2);
+                int best = INT32_MAX;
+                for (int c = half; c <= m; ++c) best = std::min(best, lv[(size_t)c]);
+                const int accept = best + best / 2 + 8; // the largest tile whose successor starts about as early as the best cut allows
+                for (int c = m; c >= half; --c)
+                    if (lv[(size_t)c] <= accept) { cut = p0 + c; break; }
             }
             tile_pos0.push_back(cut);
             p0 = cut;
@@ -446,6 +464,7 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     std::vector<int> lvl(kMaxB), order(kMaxB), cnt;
     std::vector<int32_t> ext_stamp((size_t)n, -1), ext_ord((size_t)n, 0); // per global slot: tile that listed it last, its ordinal there
     int tile_rows_max = 0;
+    int64_t n_demoted = 0;
     for (int64_t t = 0; t < n_tiles; ++t) {
         const int64_t p0 = tile_pos0[t];
         const int m = (int)(tile_pos0[t + 1] - p0);
@@ -504,6 +523,7 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                             if (qp >= p0 && (s + i) - ps <= kOwn - 128) {
                                 code[q] = ps & (kOwn - 1); // still in the ring of the tile's own results
                             } else { // another tile's result, or one of this tile's that has left the ring: through the poller
+                                if (qp >= p0) ++n_demoted;
                                 const int32_t gs = (int32_t)(tile_pos0[tile_of[(size_t)qp]] + ps);
                                 if (ext_stamp[(size_t)gs] != (int32_t)t || ext_ord[(size_t)gs] < ext_base - kExtWindow) {
                                     ext_stamp[(size_t)gs] = (int32_t)t; // first need, or last listed too long ago: next ordinal
@@ -560,6 +580,12 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
         bis_trsv_tiled_destroy(p);
         return BIS_ERR_HIP;
     }
+    if (getenv("BIS_TRSV_TILE_STATS"))
+        fprintf(stderr, "tiled sptrsv plan (%s): %lld rows, %d tiles (largest %d rows), %lld steps (%.1f rows per step), %lld quads (%.2f x the entries), "
+                        "%lld external ordinals (%.2f per row), %lld in-tile operands beyond the ring\n", backward ? "backward" : "forward",
+                (long long)n, p->n_tiles, tile_rows_max, (long long)p->n_steps, (double)n / (double)std::max<int64_t>(p->n_steps, 1),
+                (long long)p->n_quads, 4.0 * (double)p->n_quads / (double)T->nnz, (long long)p->n_ext, (double)p->n_ext / (double)n,
+                (long long)n_demoted);
     *out = p;
     return BIS_OK;
 }
