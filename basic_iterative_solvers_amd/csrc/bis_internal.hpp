@@ -77,8 +77,8 @@ struct bis_options {
     int spmv_lds_pad = -1; // diagnostic: extra dynamic LDS bytes per workgroup (lowers occupancy)
     int spmv_packed = -1;  // 16-bit packed column stream: 0 off, 1 select tree, 2 lane permute (-1: default = 1)
     int dist_host_plan = -1; // 1: bis_dist_create plans the halo on the host from the downloaded structure (default: on the device)
-    int trsv_tiled = -1;    // natural-order sweeps: 0 level-scheduled kernels of round 1, 1 (default) tiled sweep (bis_trsv_tiled.hip)
-    int trsv_tile_rows = -1; // rows per tile (default 2048)
+    int trsv_tiled = -1;    // natural-order sweeps: 1 = tiled sweep (bis_trsv_tiled.hip; opt-in: its plan is built on the host), else level-scheduled kernels
+    int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
     int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes

@@ -400,7 +400,8 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     int max_len = 0;
     for (int64_t r = 0; r < n; ++r) max_len = std::max<int>(max_len, (int)(rp[r + 1] - rp[r]));
     if ((max_len + 3) / 4 > kRingQ / 2) return BIS_OK; // a single row must fit half the quad ring
-    const int max_rows = bis_opts().trsv_tile_rows > 0 ? std::min(bis_opts().trsv_tile_rows, kMaxB) : 16384;
+    // measured (tools/trsv_ab.py): 7-point 256^3 1.46 ms at 8192 (1.65 at 4096, 1.83 at 16384); 27-point 128^3 1.18 ms at 1024, 1.24 at 2048, 1.86 at 8192
+    const int max_rows = bis_opts().trsv_tile_rows > 0 ? std::min(bis_opts().trsv_tile_rows, kMaxB) : (max_len <= 8 ? 8192 : 2048);
     // pass A: tile boundaries.  Within the second half of its allowed extent a tile is cut where the next tile's first
     // row depends only on results its predecessor produces EARLY (small local level).  Cutting in the middle of a
     // grid line would make every tile wait for the end of its predecessor and serialise the sweep (measured: 494 ms

@@ -731,3 +731,39 @@ def test_sptrsv_wave_grid_is_capped_by_residency(ctx, oracle):
         assert np.array_equal(x.to_host(), oracle.sptrsv(Us, D, b, backward=True))
     finally:
         ctx.set_option("trsv_grid", -1)
+
+
+@pytest.mark.parametrize("kind,size,rows", [("anderson", 40, -1), ("anderson", 40, 700), ("hpcg", 32, -1), ("hpcg", 32, 300),
+                                             ("fem", (14, 12, 10), -1), ("fem", (14, 12, 10), 100)])
+def test_tiled_sweep_bit_exact(ctx, oracle, kind, size, rows):
+    """The opt-in tiled natural-order sweep (`trsv_tiled`, bis_trsv_tiled.hip: tiles solved by one workgroup each,
+    in-tile operands through LDS rings, external ones through a poller wave): same CRS-order fma chain per row as
+    the reference's serial loop -> bit-exact against the fma oracle, forward and backward, also with x aliasing b
+    (gmres.hpp:173) and with tiles much smaller than the default (every ring wraps, operands leave the own-result
+    ring and come back through the poller)."""
+    A = {"anderson": lambda: oracle.gen_anderson(size, shift=9.0), "hpcg": lambda: oracle.gen_hpcg(size),
+         "fem": lambda: oracle.gen_fem(*size)}[kind]()
+    dA = {"anderson": lambda: ctx.gen_anderson(size, shift=9.0), "hpcg": lambda: ctx.gen_hpcg(size),
+          "fem": lambda: ctx.gen_fem(*size)}[kind]()
+    n = A.n_rows
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    b = np.random.default_rng(17).uniform(-1, 1, n)
+    ctx.set_option("trsv_tiled", 1)
+    ctx.set_option("trsv_tile_rows", rows)
+    try:
+        dLs, dUs, dD, dDinv = ctx.split_strict(dA)
+        db, x = ctx.upload(b), ctx.alloc(n)
+        want_f, want_b = oracle.sptrsv(Ls, D, b), oracle.sptrsv(Us, D, b, backward=True)
+        for _ in range(2):  # the second sweep reuses the plan and the scratch
+            ctx.sptrsv(dLs, x, dD, db)
+            assert np.array_equal(x.to_host(), want_f)
+            ctx.bsptrsv(dUs, x, dD, db)
+            assert np.array_equal(x.to_host(), want_b)
+        x.set(b)
+        ctx.sptrsv(dLs, x, dD, x)
+        assert np.array_equal(x.to_host(), want_f)
+        ctx.sync()
+    finally:
+        ctx.set_option("trsv_tiled", -1)
+        ctx.set_option("trsv_tile_rows", -1)
