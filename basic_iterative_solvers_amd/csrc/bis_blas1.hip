@@ -34,7 +34,8 @@ __device__ __forceinline__ double ew_apply(double a, double b, double s) {
 template <int OP, bool VEC>
 __global__ __launch_bounds__(kEwThreads) void ew3_kernel(double *r, const double *a,
                                                          const double *b, int64_t n,
-                                                         double s) {
+                                                         double s_val, const double *s_dev) {
+    const double s = s_dev ? *s_dev : s_val; // device-scalar schedules (GMRES, BiCGSTAB): the factor never visits the host
     const int64_t stride = (int64_t)gridDim.x * kEwThreads;
     int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
     if (VEC) {
@@ -59,7 +60,8 @@ enum { U_SCALE, U_COPY, U_FILL };
 
 template <int OP, bool VEC>
 __global__ __launch_bounds__(kEwThreads) void ew2_kernel(double *r, const double *a,
-                                                         int64_t n, double s) {
+                                                         int64_t n, double s_val, const double *s_dev) {
+    const double s = s_dev ? *s_dev : s_val;
     const int64_t stride = (int64_t)gridDim.x * kEwThreads;
     int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
     if (VEC) {
@@ -150,6 +152,16 @@ __global__ __launch_bounds__(256) void reduce_finish_kernel(const double *partia
     for (int i = threadIdx.x; i < n_partials; i += 256) acc += p[i];
     const double s = block_sum<256>(acc, lds);
     if (threadIdx.x == 0) result[blockIdx.x] = s;
+}
+
+// scalar algebra of the Krylov schedules, one thread: the same IEEE operations, in the same order, the reference's
+// host code performs on its doubles
+enum { SC_DIV, SC_RATIO_PRODUCT, SC_SQRT_INV };
+__global__ void scalar_kernel(int op, double *out, double *out2, const double *a, const double *b, const double *c,
+                              const double *d) {
+    if (op == SC_DIV) *out = *a / *b;                                    // bicgstab.hpp:34, :51
+    else if (op == SC_RATIO_PRODUCT) *out = (*a / *b) * (*c / *d);       // bicgstab.hpp:71
+    else { const double nrm = sqrt(*a); *out = nrm; *out2 = 1.0 / nrm; } // kernels.hpp:202, gmres.hpp:44-46
 }
 
 } // namespace
@@ -370,23 +382,23 @@ bis_status bis_vec_download(bis_ctx *ctx, double *dst, const double *src, int64_
 // ---- elementwise ----------------------------------------------------------------
 template <int OP>
 static bis_status launch_ew3(bis_ctx *ctx, double *r, const double *a, const double *b,
-                             int64_t n, double s) {
+                             int64_t n, double s, const double *s_dev = nullptr) {
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (r && a && b)), "elementwise kernel: bad arguments");
     if (n == 0) return BIS_OK;
     const bool vec = aligned16(r) && aligned16(a) && aligned16(b) && n >= 2;
     if (vec)
         hipLaunchKernelGGL((ew3_kernel<OP, true>), dim3(ew_grid(n >> 1)), dim3(kEwThreads), 0,
-                           ctx->stream, r, a, b, n, s);
+                           ctx->stream, r, a, b, n, s, s_dev);
     else
         hipLaunchKernelGGL((ew3_kernel<OP, false>), dim3(ew_grid(n)), dim3(kEwThreads), 0,
-                           ctx->stream, r, a, b, n, s);
+                           ctx->stream, r, a, b, n, s, s_dev);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
 }
 
 template <int OP>
-static bis_status launch_ew2(bis_ctx *ctx, double *r, const double *a, int64_t n, double s);
+static bis_status launch_ew2(bis_ctx *ctx, double *r, const double *a, int64_t n, double s, const double *s_dev = nullptr);
 
 extern "C" {
 
@@ -406,11 +418,22 @@ bis_status bis_elemwise_div_vectors(bis_ctx *ctx, double *r, const double *a, co
                                     int64_t n, double scale) {
     return launch_ew3<OP_DIV>(ctx, r, a, b, n, scale);
 }
+// device-scalar forms: the factor is read from device memory when the kernel runs
+bis_status bis_subtract_vectors_dev(bis_ctx *ctx, double *r, const double *a, const double *b,
+                                    int64_t n, const double *scale_dev) {
+    BIS_REQUIRE(ctx, scale_dev, "bis_subtract_vectors_dev: null scalar");
+    return launch_ew3<OP_SUB>(ctx, r, a, b, n, 0.0, scale_dev);
+}
+bis_status bis_sum_vectors_dev(bis_ctx *ctx, double *r, const double *a, const double *b, int64_t n,
+                               const double *scale_dev) {
+    BIS_REQUIRE(ctx, scale_dev, "bis_sum_vectors_dev: null scalar");
+    return launch_ew3<OP_SUM>(ctx, r, a, b, n, 0.0, scale_dev);
+}
 
 } // extern "C"
 
 template <int OP>
-static bis_status launch_ew2(bis_ctx *ctx, double *r, const double *a, int64_t n, double s) {
+static bis_status launch_ew2(bis_ctx *ctx, double *r, const double *a, int64_t n, double s, const double *s_dev) {
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (r && (a || OP == U_FILL))),
                 "elementwise kernel: bad arguments");
@@ -418,10 +441,10 @@ static bis_status launch_ew2(bis_ctx *ctx, double *r, const double *a, int64_t n
     const bool vec = aligned16(r) && (OP == U_FILL || aligned16(a)) && n >= 2;
     if (vec)
         hipLaunchKernelGGL((ew2_kernel<OP, true>), dim3(ew_grid(n >> 1)), dim3(kEwThreads), 0,
-                           ctx->stream, r, a, n, s);
+                           ctx->stream, r, a, n, s, s_dev);
     else
         hipLaunchKernelGGL((ew2_kernel<OP, false>), dim3(ew_grid(n)), dim3(kEwThreads), 0,
-                           ctx->stream, r, a, n, s);
+                           ctx->stream, r, a, n, s, s_dev);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
 }
@@ -430,6 +453,10 @@ extern "C" {
 
 bis_status bis_scale(bis_ctx *ctx, double *r, const double *v, double scalar, int64_t n) {
     return launch_ew2<U_SCALE>(ctx, r, v, n, scalar);
+}
+bis_status bis_scale_dev(bis_ctx *ctx, double *r, const double *v, const double *scalar_dev, int64_t n) {
+    BIS_REQUIRE(ctx, scalar_dev, "bis_scale_dev: null scalar");
+    return launch_ew2<U_SCALE>(ctx, r, v, n, 0.0, scalar_dev);
 }
 bis_status bis_init_vector(bis_ctx *ctx, double *v, double val, int64_t n) {
     return launch_ew2<U_FILL>(ctx, v, nullptr, n, val);
@@ -505,6 +532,32 @@ bis_status bis_euclidean_vec_norm(bis_ctx *ctx, const double *v, int64_t n,
     bis_status st = bis_dot(ctx, v, v, n, &ss);
     if (st != BIS_OK) return st;
     *result_host = sqrt(ss); // kernels.hpp:202
+    return BIS_OK;
+}
+
+bis_status bis_scalar_div(bis_ctx *ctx, double *out_dev, const double *a_dev, const double *b_dev) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, out_dev && a_dev && b_dev, "bis_scalar_div: bad arguments");
+    hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(1), 0, ctx->stream, (int)SC_DIV, out_dev, (double *)nullptr, a_dev, b_dev,
+                       (const double *)nullptr, (const double *)nullptr);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+bis_status bis_scalar_ratio_product(bis_ctx *ctx, double *out_dev, const double *a_dev, const double *b_dev,
+                                    const double *c_dev, const double *d_dev) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, out_dev && a_dev && b_dev && c_dev && d_dev, "bis_scalar_ratio_product: bad arguments");
+    hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(1), 0, ctx->stream, (int)SC_RATIO_PRODUCT, out_dev, (double *)nullptr, a_dev, b_dev,
+                       c_dev, d_dev);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}
+bis_status bis_scalar_sqrt_inv(bis_ctx *ctx, double *norm_dev, double *inv_dev, const double *sumsq_dev) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, norm_dev && inv_dev && sumsq_dev, "bis_scalar_sqrt_inv: bad arguments");
+    hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(1), 0, ctx->stream, (int)SC_SQRT_INV, norm_dev, inv_dev, sumsq_dev,
+                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
 }
 

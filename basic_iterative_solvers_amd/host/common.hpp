@@ -76,6 +76,8 @@ struct Args {
     int restart_length = 10;
     bool num_scale = false;
     bool unfused = false; // -unfused: CG runs the reference's kernel-by-kernel schedule
+    bool host_scalars = false; // -hostscalars: GMRES / BiCGSTAB return every dot product to the host like the reference
+                               // (default: Gram-Schmidt coefficients, alpha / omega / beta stay on the device)
     std::string perm_mode = "none"; // -perm mc: multi-colour reordering (SMAX PERM_MODE role)
     std::string dump_perm;          // -dump-perm FILE: write perm[new]=old
     std::string dump_x;             // -dump-x FILE: write x* (natural row order, also after -perm)

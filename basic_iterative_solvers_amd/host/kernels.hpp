@@ -93,6 +93,28 @@ inline void apply_preconditioner(const PrecondType pc, const int N, const Matrix
                                         PRECOND_INNER_ITERS), "apply_preconditioner");
 }
 
+// ---- device-scalar forms (this build's addition): the factor / the result lives in device memory, no host round trip.
+// Same kernels and the same IEEE operations in the same order as the host-scalar functions above.
+inline void dot_dev(const double *a, const double *b, const int N, double *result_dev) {
+    bis::check(bis_dot_dev(bis::ctx(), a, b, N, result_dev), "dot_dev");
+}
+inline void subtract_vectors_dev(double *r, const double *a, const double *b, const int N, const double *scale_dev) {
+    bis::check(bis_subtract_vectors_dev(bis::ctx(), r, a, b, N, scale_dev), "subtract_vectors_dev");
+}
+inline void sum_vectors_dev(double *r, const double *a, const double *b, const int N, const double *scale_dev) {
+    bis::check(bis_sum_vectors_dev(bis::ctx(), r, a, b, N, scale_dev), "sum_vectors_dev");
+}
+inline void scale_dev(double *r, const double *v, const double *scalar_dev, const int N) {
+    bis::check(bis_scale_dev(bis::ctx(), r, v, scalar_dev, N), "scale_dev");
+}
+inline void scalar_div(double *out, const double *a, const double *b) { bis::check(bis_scalar_div(bis::ctx(), out, a, b), "scalar_div"); }
+inline void scalar_ratio_product(double *out, const double *a, const double *b, const double *c, const double *d) {
+    bis::check(bis_scalar_ratio_product(bis::ctx(), out, a, b, c, d), "scalar_ratio_product");
+}
+inline void scalar_sqrt_inv(double *norm, double *inv, const double *sumsq) {
+    bis::check(bis_scalar_sqrt_inv(bis::ctx(), norm, inv, sumsq), "scalar_sqrt_inv");
+}
+
 // ---- small dense helpers of GMRES: stay on the host (<= 51x51), kernels.hpp:222-310
 inline void init_dense_identity_matrix(double *m, int r, int c) {
     for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) m[c * i + j] = i == j ? 1.0 : 0.0;

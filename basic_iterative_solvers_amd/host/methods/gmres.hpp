@@ -23,6 +23,23 @@ inline void orthogonalize_V(Timers *timers, int N, int n, int m, double *H, doub
     TIME(timers, "scale", scale(&V[(long)(n + 1) * N], w, 1.0 / hn1, N))
 }
 
+// The same modified Gram-Schmidt step with its coefficients kept on the device: j+2 stream-ordered reductions, the
+// axpys read their factor from device memory, ONE download of the Hessenberg column (the host-side Givens algebra needs
+// it) instead of j+2 blocking dots.  Same kernels, same operation order: H and V come out bit-identical.
+inline void orthogonalize_V_dev(Timers *, int N, int n, int m, double *H, double *V, double *w, double *hcol_dev,
+                                double *hcol_host) {
+    for (int j = 0; j <= n; ++j) {
+        dot_dev(w, &V[(long)j * N], N, hcol_dev + j);                        // gmres.hpp:13-14
+        subtract_vectors_dev(w, w, &V[(long)j * N], N, hcol_dev + j);        // :25
+    }
+    dot_dev(w, w, N, hcol_dev + n + 1);                                      // :36-38 (sum of squares ...
+    scalar_sqrt_inv(hcol_dev + n + 1, hcol_dev + n + 2, hcol_dev + n + 1);   //  ... its root, and 1/root)
+    scale_dev(&V[(long)(n + 1) * N], w, hcol_dev + n + 2, N);                // :44-46
+    to_host(hcol_host, hcol_dev, n + 2);
+    for (int j = 0; j <= n; ++j) H[n + j * m] = hcol_host[j];
+    H[(n + 1) * m + n] = hcol_host[n + 1];
+}
+
 inline void least_squares(Timers *timers, int n, int m, double *J, double *H, double *H_tmp, double *Q,
                           double *Q_tmp, double *R) {
     init_dense_identity_matrix(J, m + 1, m + 1);
@@ -57,13 +74,17 @@ class GMRESSolver : public Solver {
     double *y = nullptr, *H = nullptr, *H_tmp = nullptr, *J = nullptr, *Q = nullptr, *Q_tmp = nullptr,
            *R = nullptr, *g = nullptr, *g_tmp = nullptr; // host
     double beta = 0.0;
+    bool dev_scalars = true;
+    double *hcol_dev = nullptr, *hcol_host = nullptr; // one Hessenberg column: h_0..h_n, ||w||, 1/||w||
 
-    explicit GMRESSolver(const Args *a) : Solver(a) {}
+    explicit GMRESSolver(const Args *a) : Solver(a), dev_scalars(!a->host_scalars) {}
     void allocate_structs(const int n) override {
         Solver::allocate_structs(n);
         const int m = gmres_restart_len;
         x = dalloc(n); x_old = dalloc(n); V = dalloc((long)n * (m + 1)); Vy = dalloc(n); w = dalloc(n);
         y = new double[m];
+        hcol_dev = dalloc(m + 4);
+        hcol_host = new double[m + 4];
         H = new double[(m + 1) * m]; H_tmp = new double[(m + 1) * m]; R = new double[(m + 1) * m];
         J = new double[(m + 1) * (m + 1)]; Q = new double[(m + 1) * (m + 1)]; Q_tmp = new double[(m + 1) * (m + 1)];
         g = new double[m + 1]; g_tmp = new double[m + 1];
@@ -109,7 +130,8 @@ class GMRESSolver : public Solver {
         TIME(timers, "spmv", spmv(A.get(), &V[(long)n * N], w))
         TIME(timers, "precond", apply_preconditioner(preconditioner, N, L_strict.get(), U_strict.get(), A_D,
                                                      A_D_inv, L_D, U_D, w, w, tmp, work))
-        TIME(timers, "orthog", orthogonalize_V(timers, N, n, m, H, V, w))
+        if (dev_scalars) { TIME(timers, "orthog", orthogonalize_V_dev(timers, N, n, m, H, V, w, hcol_dev, hcol_host)) }
+        else { TIME(timers, "orthog", orthogonalize_V(timers, N, n, m, H, V, w)) }
         TIME(timers, "least_sq", least_squares(timers, n, m, J, H, H_tmp, Q, Q_tmp, R))
         TIME(timers, "update_g", update_g(timers, n, m, Q, g, g_tmp, residual_norm, beta))
     }
@@ -149,7 +171,8 @@ class GMRESSolver : public Solver {
     }
     void exchange() override {}
     ~GMRESSolver() override {
-        dfree(x); dfree(x_old); dfree(V); dfree(Vy); dfree(w);
+        dfree(x); dfree(x_old); dfree(V); dfree(Vy); dfree(w); dfree(hcol_dev);
+        delete[] hcol_host;
         delete[] y; delete[] H; delete[] H_tmp; delete[] J; delete[] Q; delete[] Q_tmp; delete[] R;
         delete[] g; delete[] g_tmp;
     }

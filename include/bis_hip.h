@@ -252,6 +252,33 @@ BIS_API bis_status bis_dot_dev(bis_ctx *ctx, const double *a, const double *b,
                                int64_t n, double *result_dev);
 BIS_API bis_status bis_sumsq_dev(bis_ctx *ctx, const double *v, int64_t n,
                                  double *result_dev);
+/* Device-scalar forms of the axpy-class kernels and the scalar algebra around
+ * them: the factor is read from device memory when the kernel runs, so a
+ * Krylov iteration needs no host round trip per dot product.  GMRES: the
+ * modified Gram-Schmidt step (gmres.hpp:6-53: h = (w,v_j); w -= h v_j; ... ;
+ * v_{n+1} = w * (1/||w||)) is j+2 stream-ordered reductions and ONE download
+ * of the Hessenberg column instead of j+2 blocking dots; BiCGSTAB
+ * (bicgstab.hpp:8-83): alpha, omega, beta stay on the device.  Same kernels,
+ * same IEEE operations in the same order as the host-scalar forms: results
+ * are bit-identical to them. */
+BIS_API bis_status bis_subtract_vectors_dev(bis_ctx *ctx, double *r, const double *a,
+                                            const double *b, int64_t n,
+                                            const double *scale_dev);
+BIS_API bis_status bis_sum_vectors_dev(bis_ctx *ctx, double *r, const double *a,
+                                       const double *b, int64_t n,
+                                       const double *scale_dev);
+BIS_API bis_status bis_scale_dev(bis_ctx *ctx, double *r, const double *v,
+                                 const double *scalar_dev, int64_t n);
+/* out = a / b  (alpha, omega: bicgstab.hpp:34, :51) */
+BIS_API bis_status bis_scalar_div(bis_ctx *ctx, double *out_dev, const double *a_dev,
+                                  const double *b_dev);
+/* out = (a / b) * (c / d)  (beta: bicgstab.hpp:71) */
+BIS_API bis_status bis_scalar_ratio_product(bis_ctx *ctx, double *out_dev,
+                                            const double *a_dev, const double *b_dev,
+                                            const double *c_dev, const double *d_dev);
+/* norm = sqrt(sumsq), inv = 1.0 / norm  (kernels.hpp:202, gmres.hpp:44-46) */
+BIS_API bis_status bis_scalar_sqrt_inv(bis_ctx *ctx, double *norm_dev, double *inv_dev,
+                                       const double *sumsq_dev);
 /* scale, kernels.hpp:214-220: r = v*scalar. */
 BIS_API bis_status bis_scale(bis_ctx *ctx, double *r, const double *v,
                              double scalar, int64_t n);

@@ -223,3 +223,16 @@ def test_cli_perm_returns_x_star_in_natural_order(tmp_path, mode, extra, name, s
     scale = np.max(np.abs(x0))
     assert np.max(np.abs(x1 - x0)) <= 1e-9 * scale         # ... and x* is back in natural order
     assert np.max(np.abs(x1[perm] - x0)) > 1e-6 * scale    # (the still-permuted vector would not pass)
+
+
+@pytest.mark.parametrize("name,solver,pc,kw", [("hpcg8", "gm", "gs", {"restart_len": 10}), ("FDM-2d-16", "gm", "none", {"restart_len": 30}),
+                                               ("anderson8_shift9", "bi", "ilu0", {}), ("hpcg_4x6x5", "bi", "sgs", {}),
+                                               ("matrix_band_klein", "bi", "j", {})])
+def test_cli_device_scalar_schedules_match_host_scalar_ones(name, solver, pc, kw):
+    """GMRES keeps its Gram-Schmidt coefficients, BiCGSTAB its rho / alpha / omega / beta on the device (one blocking
+    read per iteration instead of j+2 / 6); `-hostscalars` returns every dot product to the host like the reference.
+    Same kernels, same IEEE operations in the same order: the printed residual tables are identical digit for digit."""
+    a = run_cli(name, solver, pc, kw)
+    b = run_cli(name, solver, pc, kw, extra=["-hostscalars"])
+    assert a["iters"] == b["iters"] and a["converged"] == b["converged"]
+    assert np.array_equal(a["hist"], b["hist"])
