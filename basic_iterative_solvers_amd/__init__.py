@@ -144,6 +144,28 @@ class Context:
         store.free()
         return Mat(self, h), perm, nc.value
 
+    def bfs_order(self, A, rcm=False):
+        """Breadth-first / reverse Cuthill-McKee permutation on the device (perm[new] = old, numpy int32)."""
+        n = A.n_rows
+        store = self.alloc((n + 1) // 2 + 1)
+        self.check(self.lib.bis_mat_bfs_order(self.h, A.h, C.c_int(int(rcm)), C.c_void_p(store.ptr)))
+        perm = store.to_host().view(np.int32)[:n].copy()
+        store.free()
+        return perm
+
+    def permute(self, A, perm):
+        """B = P A P^T on the device for perm[new] = old."""
+        n = len(perm)
+        raw = np.zeros((n + 1) // 2 + 1)
+        raw.view(np.int32)[:n] = np.asarray(perm, dtype=np.int32)
+        store = self.upload(raw)
+        h = C.c_void_p()
+        try:
+            self.check(self.lib.bis_mat_permute(self.h, A.h, C.c_void_p(store.ptr), C.byref(h)))
+        finally:
+            store.free()
+        return Mat(self, h)
+
     def scale_sym(self, A, init=0.0):
         """-scale on the device: returns the scale vector s (Vec); A's values are scaled in place."""
         s = self.alloc(A.n_rows)

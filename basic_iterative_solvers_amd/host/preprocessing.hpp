@@ -134,25 +134,54 @@ inline void preprocessing(Args *cli_args, Solver *solver, Timers *timers, std::u
         if (!cli_args->dump_perm.empty()) write_permutation(cli_args->dump_perm, perm);
         std::cout << "multi-colour reordering: " << n_colours << " colours" << std::endl;
     } else if (cli_args->perm_mode == "rcm" || cli_args->perm_mode == "bfs") {
-        // bandwidth-reducing orderings (host, setup only): they keep the sweeps level-scheduled, with
-        // fewer or more levels than the natural order depending on the input
+        // bandwidth-reducing orderings: they keep the sweeps level-scheduled, with fewer or more levels than the
+        // natural order depending on the input.  On the device (level-synchronous BFS, bis_order.hip) for structurally
+        // symmetric patterns; the sequential host version otherwise, or with -perm-host.
         const int N = solver->A->n_rows;
-        download_to_host(solver->A.get());
-        std::vector<int> perm, inv_perm;
-        bfs_like_permutation(solver->A.get(), cli_args->perm_mode == "rcm", perm, inv_perm);
-        auto B = std::make_unique<MatrixCRS>();
-        permute_matrix(solver->A.get(), perm, inv_perm, B.get());
-        B->upload();
-        solver->A = std::move(B);
-        if (solver->num_scale) {
-            std::vector<double> hb(N), pb(N);
-            to_host(hb.data(), solver->b, N);
-            for (int i = 0; i < N; ++i) pb[i] = hb[perm[i]];
-            to_device(solver->b, pb.data(), N);
+        const bool rcm = cli_args->perm_mode == "rcm";
+        std::vector<int> perm;
+        double *perm_store = dalloc((N + 1) / 2 + 1);
+        int32_t *perm_dev = reinterpret_cast<int32_t *>(perm_store);
+        bis_status dev = cli_args->perm_host ? BIS_ERR_UNSUPPORTED : bis_mat_bfs_order(bis::ctx(), solver->A->dev, rcm ? 1 : 0, perm_dev);
+        if (dev != BIS_OK && dev != BIS_ERR_UNSUPPORTED) bis::check(dev, "bis_mat_bfs_order");
+        if (dev == BIS_OK) {
+            bis_mat *Bm = nullptr;
+            bis::check(bis_mat_permute(bis::ctx(), solver->A->dev, perm_dev, &Bm), "bis_mat_permute");
+            auto B = std::make_unique<MatrixCRS>();
+            B->adopt(Bm);
+            solver->A = std::move(B);
+            if (solver->num_scale) { // b was rescaled row-wise: permute it (x_0 is constant)
+                double *pb = dalloc(N);
+                bis::check(bis_vec_gather(bis::ctx(), pb, solver->b, perm_dev, N), "bis_vec_gather");
+                copy_vector(solver->b, pb, N);
+                dfree(pb);
+            }
+            solver->perm_store = perm_store;
+            if (!cli_args->dump_perm.empty()) {
+                std::vector<double> raw((N + 1) / 2 + 1);
+                to_host(raw.data(), perm_store, (N + 1) / 2 + 1);
+                const int32_t *pp = reinterpret_cast<const int32_t *>(raw.data());
+                perm.assign(pp, pp + N);
+            }
+        } else {
+            dfree(perm_store);
+            download_to_host(solver->A.get());
+            std::vector<int> inv_perm;
+            bfs_like_permutation(solver->A.get(), rcm, perm, inv_perm);
+            auto B = std::make_unique<MatrixCRS>();
+            permute_matrix(solver->A.get(), perm, inv_perm, B.get());
+            B->upload();
+            solver->A = std::move(B);
+            if (solver->num_scale) {
+                std::vector<double> hb(N), pb(N);
+                to_host(hb.data(), solver->b, N);
+                for (int i = 0; i < N; ++i) pb[i] = hb[perm[i]];
+                to_device(solver->b, pb.data(), N);
+            }
+            solver->keep_permutation(perm);
         }
-        solver->keep_permutation(perm);
         if (!cli_args->dump_perm.empty()) write_permutation(cli_args->dump_perm, perm);
-        std::cout << (cli_args->perm_mode == "rcm" ? "reverse Cuthill-McKee" : "breadth-first") << " reordering" << std::endl;
+        std::cout << (rcm ? "reverse Cuthill-McKee" : "breadth-first") << " reordering" << (dev == BIS_OK ? "" : " (host)") << std::endl;
     } else if (cli_args->perm_mode != "none") {
         fprintf(stderr, "ERROR: unknown -perm mode (available: mc, rcm, bfs)\n");
         exit(EXIT_FAILURE);

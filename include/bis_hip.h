@@ -194,6 +194,20 @@ BIS_API bis_status bis_mat_multicolour(bis_ctx *ctx, const bis_mat *A,
                                        int *n_colours);
 BIS_API bis_status bis_vec_gather(bis_ctx *ctx, double *out, const double *in,
                                   const int32_t *perm_dev, int64_t n);
+/* Breadth-first (rcm = 0) or reverse Cuthill-McKee (rcm = 1) ordering on the
+ * device (SMAX PERM_MODE BFS / RCM roles, CMakeLists.txt:128-133): perm[new] =
+ * old written to perm_dev (n int32).  Level-synchronous, and entry for entry
+ * the permutation of the sequential queue algorithm (components from the
+ * lowest-numbered / lowest-degree unseen vertex, neighbours in ascending index
+ * / ascending (degree, index) order).  Structurally symmetric patterns with
+ * at most 64 connected components; otherwise BIS_ERR_UNSUPPORTED (the host
+ * layer then runs the sequential version).
+ * bis_mat_permute: B = P A P^T for any permutation (entries keep their order
+ * inside a row, columns renumbered); BIS_ERR_INVALID if perm is not one. */
+BIS_API bis_status bis_mat_bfs_order(bis_ctx *ctx, const bis_mat *A, int rcm,
+                                     int32_t *perm_dev);
+BIS_API bis_status bis_mat_permute(bis_ctx *ctx, const bis_mat *A,
+                                   const int32_t *perm_dev, bis_mat **B);
 /* out[perm[i]] = in[i]: the inverse permutation without forming it -- returns
  * x* of a permuted solve in the caller's original row order (the reference's
  * SMAX path leaves x* permuted, smax_helpers.hpp:44-80).  out != in. */

@@ -767,3 +767,72 @@ def test_tiled_sweep_bit_exact(ctx, oracle, kind, size, rows):
     finally:
         ctx.set_option("trsv_tiled", -1)
         ctx.set_option("trsv_tile_rows", -1)
+
+
+def _queue_order(A, rcm):
+    """The sequential definition of the two orderings (host/utilities/permute.hpp bfs_like_permutation)."""
+    n = A.n_rows
+    adj = [set() for _ in range(n)]
+    for r in range(n):
+        for c in A.col[A.row_ptr[r]:A.row_ptr[r + 1]]:
+            if c != r:
+                adj[r].add(int(c)); adj[int(c)].add(r)
+    adj = [sorted(a) for a in adj]
+    deg = [len(a) for a in adj]
+    starts = sorted(range(n), key=lambda v: deg[v]) if rcm else list(range(n))
+    seen, perm = [False] * n, []
+    for s0 in starts:
+        if seen[s0]:
+            continue
+        seen[s0] = True
+        head = len(perm)
+        perm.append(s0)
+        while head < len(perm):
+            v = perm[head]; head += 1
+            nb = [w for w in adj[v] if not seen[w]]
+            for w in nb:
+                seen[w] = True
+            if rcm:
+                nb.sort(key=lambda w: deg[w])
+            perm += nb
+    return np.array(perm[::-1] if rcm else perm, dtype=np.int32)
+
+
+@pytest.mark.parametrize("rcm", [False, True])
+@pytest.mark.parametrize("kind", ["hpcg", "anderson", "fem", "klein", "components"])
+def test_device_bfs_rcm_ordering(ctx, oracle, kind, rcm):
+    """bis_mat_bfs_order: the level-synchronous device ordering equals the sequential queue algorithm entry for
+    entry (also across several connected components), and bis_mat_permute builds P A P^T with the row-internal
+    entry order kept."""
+    if kind == "klein":
+        A = crs_of(load_golden("matrix_band_klein"), "A")
+    elif kind == "components":  # three disconnected 7-point grids of different sizes -> three BFS restarts
+        import scipy.sparse as sp
+        parts = [oracle.gen_anderson(L, shift=9.0).to_scipy() for L in (4, 3, 5)]
+        M = sp.block_diag(parts, format="csr")
+        A = CRS(M.shape[0], M.indptr, M.indices.astype(np.int32), M.data)
+    else:
+        A = {"hpcg": lambda: oracle.gen_hpcg(9, 7, 8), "anderson": lambda: oracle.gen_anderson(8, shift=9.0),
+             "fem": lambda: oracle.gen_fem(7, 6, 5)}[kind]()
+    n = A.n_rows
+    dA = ctx.matrix(A)
+    perm = ctx.bfs_order(dA, rcm)
+    assert np.array_equal(perm, _queue_order(A, rcm))
+    dB = ctx.permute(dA, perm)
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    rp, col, val = dB.download()
+    lens = np.diff(A.row_ptr)[perm]
+    assert np.array_equal(rp, np.concatenate([[0], np.cumsum(lens)]))
+    assert np.array_equal(col, np.concatenate([inv[A.col[A.row_ptr[o]:A.row_ptr[o + 1]]] for o in perm]))
+    assert np.array_equal(val, np.concatenate([A.val[A.row_ptr[o]:A.row_ptr[o + 1]] for o in perm]))
+
+
+def test_device_bfs_refuses_unsymmetric_patterns_and_bad_permutations(ctx):
+    from basic_iterative_solvers_amd import BisError
+    A = CRS(3, [0, 2, 3, 4], [0, 1, 1, 2], [1.0, 2.0, 3.0, 4.0])  # (0,1) without (1,0)
+    dA = ctx.matrix(A)
+    with pytest.raises(BisError, match="structurally symmetric"):
+        ctx.bfs_order(dA)
+    with pytest.raises(BisError, match="not a permutation"):
+        ctx.permute(dA, np.array([0, 0, 2], dtype=np.int32))

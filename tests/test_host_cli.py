@@ -236,3 +236,20 @@ def test_cli_device_scalar_schedules_match_host_scalar_ones(name, solver, pc, kw
     b = run_cli(name, solver, pc, kw, extra=["-hostscalars"])
     assert a["iters"] == b["iters"] and a["converged"] == b["converged"]
     assert np.array_equal(a["hist"], b["hist"])
+
+
+@pytest.mark.parametrize("mode,name,solver,pc,scale", [("rcm", "FDM-2d-16", "cg", "sgs", True), ("bfs", "hpcg_4x6x5", "gm", "gs", False),
+                                                       ("rcm", "anderson8_shift9", "bi", "ilu0", True), ("bfs", "matrix_band_klein", "gs", "none", False)])
+def test_cli_device_and_host_rcm_bfs_agree(tmp_path, mode, name, solver, pc, scale):
+    """-perm rcm|bfs on the device (bis_mat_bfs_order + bis_mat_permute) and the sequential host version (-perm-host)
+    produce the same permutation file and residual tables that agree to rounding of the device reductions."""
+    kw = {"num_scale": True} if scale else {}
+    if solver == "gm":
+        kw["restart_len"] = 30
+    f1, f2 = str(tmp_path / "p_dev.txt"), str(tmp_path / "p_host.txt")
+    a = run_cli(name, solver, pc, kw, extra=["-perm", mode, "-dump-perm", f1])
+    b = run_cli(name, solver, pc, kw, extra=["-perm", mode, "-perm-host", "-dump-perm", f2])
+    assert "(host)" not in a["stdout"] and "(host)" in b["stdout"]
+    assert np.array_equal(np.loadtxt(f1, dtype=np.int64), np.loadtxt(f2, dtype=np.int64))
+    assert a["iters"] == b["iters"] and len(a["hist"]) == len(b["hist"])
+    assert np.max(np.abs(a["hist"] - b["hist"])) <= 1e-12 * a["hist"][0]
