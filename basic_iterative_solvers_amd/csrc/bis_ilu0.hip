@@ -206,6 +206,17 @@ __global__ __launch_bounds__(256) void ilu0_level_wave_kernel(const RP *__restri
     if (lane == 0) { U_D[i] = u_diag; L_D[i] = 1.0; }
 }
 
+// rows of the sorted copy with a repeated column: the wave-per-row kernel locates ONE entry per column by binary search,
+// the reference's serial loop updates every copy -- such matrices take the lane-per-row kernel
+template <typename RP>
+__global__ __launch_bounds__(256) void dup_check_kernel(const RP *__restrict__ rp, const int32_t *__restrict__ wcol, int64_t n, int *flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool dup = false;
+    for (int64_t p = (int64_t)rp[i] + 1; p < (int64_t)rp[i + 1]; ++p) dup |= wcol[p] == wcol[p - 1];
+    if (dup) atomicOr(flag, 1);
+}
+
 template <typename RP>
 bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot_repl, bis_mat **Ls_out,
                   bis_mat **Us_out, double *L_D, double *U_D) {
@@ -235,6 +246,15 @@ bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot
             hipLaunchKernelGGL(sort_rows_kernel<RP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const RP *)A->row_ptr, A->col, A->val, n, W->col, W->val, dpos, ustart);
     }
+    int has_dups = 0;
+    if (n > 0) {
+        int *flag = (int *)ctx->counters + 38;
+        hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
+        hipLaunchKernelGGL(dup_check_kernel<RP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rp, W->col, n, flag);
+        e = hipMemcpyAsync(&has_dups, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->err = std::string("bis_mat_ilu0: ") + hipGetErrorString(e); return cleanup(BIS_ERR_HIP); }
+    }
     st = bis_mat_finalize(ctx, W);
     if (st != BIS_OK) return cleanup(st);
     // dependency levels = levels of the strict lower triangle of the pattern
@@ -248,7 +268,7 @@ bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot
         const int nl = (int)level_ptr->size() - 1;
         for (int l = 0; l < nl; ++l) {
             const int64_t lo = (*level_ptr)[l], hi = (*level_ptr)[l + 1];
-            if (W->max_row_nnz <= kIluMaxRow && bis_opts().ilu0_wave != 0) {
+            if (W->max_row_nnz <= kIluMaxRow && bis_opts().ilu0_wave != 0 && !has_dups) {
                 const int mr = std::max(W->max_row_nnz, 1);
                 hipLaunchKernelGGL(ilu0_level_wave_kernel<RP>, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256),
                                    (size_t)4 * mr * (sizeof(double) + sizeof(int32_t)), ctx->stream, rp, W->col,

@@ -49,6 +49,23 @@ __global__ void row_blocks_kernel(const RP *row_ptr, int64_t n_rows, int n_block
     blk_nnz[k] = (int64_t)row_ptr[lo];
 }
 
+// structure check of an uploaded CRS: status |= 1 row_ptr not monotone / wrong ends, |= 2 column out of range
+template <typename RP>
+__global__ __launch_bounds__(256) void validate_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col, int64_t n_rows,
+                                                       int64_t n_cols, int64_t nnz, int *status) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t a = (int64_t)row_ptr[r], b = (int64_t)row_ptr[r + 1];
+    int bad = 0;
+    if (a > b || a < 0 || b > nnz || (r == 0 && a != 0) || (r == n_rows - 1 && b != nnz)) bad |= 1;
+    else
+        for (int64_t k = a; k < b; ++k) {
+            const int64_t c = col[k];
+            if (c < 0 || c >= n_cols) bad |= 2;
+        }
+    if (bad) atomicOr(status, bad);
+}
+
 // ---- generators ---------------------------------------------------------------
 __device__ __forceinline__ int64_t hpcg_c(int64_t j, int64_t n) { return 1 + (j > 0) + (j < n - 1); }
 __device__ __forceinline__ int64_t hpcg_f(int64_t k, int64_t n) {
@@ -486,6 +503,28 @@ static bis_status mat_create_common(bis_ctx *ctx, int64_t n_rows, int64_t n_cols
         bis_mat_destroy(ctx, A);
         return BIS_ERR_HIP;
     }
+    // a malformed input must be an error here, not an out-of-bounds gather in a kernel later
+    if (n_rows > 0) {
+        int *status = (int *)ctx->counters + 36;
+        hipMemsetAsync(status, 0, sizeof(int), ctx->stream);
+        const unsigned grid = (unsigned)((n_rows + 255) / 256);
+        if (rp64) hipLaunchKernelGGL(validate_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, n_rows, n_cols, nnz, status);
+        else hipLaunchKernelGGL(validate_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, n_rows, n_cols, nnz, status);
+        int h = 0;
+        e = hipMemcpyAsync(&h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->err = std::string("bis_mat_create: ") + hipGetErrorString(e); bis_mat_destroy(ctx, A); return BIS_ERR_HIP; }
+        if (h) {
+            ctx->err = (h & 1) ? "bis_mat_create: row_ptr is not a monotone sequence from 0 to nnz"
+                               : "bis_mat_create: column index outside [0, n_cols)";
+            bis_mat_destroy(ctx, A);
+            return BIS_ERR_INVALID;
+        }
+    } else if (nnz != 0) {
+        ctx->err = "bis_mat_create: non-zeros without rows";
+        bis_mat_destroy(ctx, A);
+        return BIS_ERR_INVALID;
+    }
     st = bis_mat_finalize(ctx, A);
     if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
     *out = A;
@@ -533,6 +572,9 @@ BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_tria
                                           double *best_ms) {
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, A && !A->view, "bis_mat_tune_placement: owning matrix required");
+    // the streamed arrays are re-allocated: row views made earlier -- the triangular-solve plans cache some -- would
+    // keep pointing at the freed ones
+    BIS_REQUIRE(ctx, !A->plan_fwd && !A->plan_bwd, "bis_mat_tune_placement: call it before the first triangular solve on this matrix");
     if (first_ms) *first_ms = 0.0;
     if (best_ms) *best_ms = 0.0;
     if (A->nnz == 0 || A->n_rows == 0 || max_trials <= 0) return BIS_OK;

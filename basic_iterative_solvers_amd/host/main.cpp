@@ -25,7 +25,7 @@ static void run(Args *cli_args, Timers *timers) {
     }
     auto A = std::make_unique<MatrixCRS>();
     if (!make_generated_matrix(cli_args->matrix_file_name, A.get())) {
-        if (cli_args->crs_cache.empty() || !read_crs_cache(cli_args->crs_cache, A.get())) {
+        if (cli_args->crs_cache.empty() || !read_crs_cache(cli_args->crs_cache, cli_args->matrix_file_name, A.get())) {
             MatrixCOO mtx;
             try {
                 mtx.read_from_mtx(cli_args->matrix_file_name);
@@ -34,7 +34,7 @@ static void run(Args *cli_args, Timers *timers) {
                 exit(EXIT_FAILURE);
             }
             convert_coo_to_crs(&mtx, A.get());
-            if (!cli_args->crs_cache.empty()) write_crs_cache(cli_args->crs_cache, A.get());
+            if (!cli_args->crs_cache.empty()) write_crs_cache(cli_args->crs_cache, cli_args->matrix_file_name, A.get());
         }
         A->upload();
     }

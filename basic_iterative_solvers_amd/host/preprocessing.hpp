@@ -12,37 +12,29 @@
 
 inline void download_to_host(MatrixCRS *A) { // device-generated matrix -> host arrays (setup only)
     if (A->row_ptr) return;
-    std::vector<int64_t> rp(A->n_rows + 1);
-    A->row_ptr = new int[A->n_rows + 1];
+    A->row_ptr = new crs_index[A->n_rows + 1];
     A->col = new int[A->nnz ? A->nnz : 1];
     A->val = new double[A->nnz ? A->nnz : 1];
-    bis::check(bis_mat_download(bis::ctx(), A->dev, rp.data(), A->col, A->val), "bis_mat_download");
-    for (int i = 0; i <= A->n_rows; ++i) A->row_ptr[i] = (int)rp[i];
+    bis::check(bis_mat_download(bis::ctx(), A->dev, A->row_ptr, A->col, A->val), "bis_mat_download");
 }
 
 inline void scale_mat(MatrixCRS *A, const double *s) { // preprocessing.hpp:15-24
     for (int r = 0; r < A->n_rows; ++r)
-        for (int i = A->row_ptr[r]; i < A->row_ptr[r + 1]; ++i) A->val[i] *= (s[r] * s[A->col[i]]);
+        for (crs_index i = A->row_ptr[r]; i < A->row_ptr[r + 1]; ++i) A->val[i] *= (s[r] * s[A->col[i]]);
 }
 
 // factor_LU, utilities/LU_factors.hpp:900-934
 inline void factor_LU(Solver *s) {
-    const int N = s->A->n_rows;
-    if (!s->A->row_ptr) {
-        // device-resident input: split + diagonal on the device
+    // split + diagonal on the device (bis_mat_split_strict: bit-identical to the reference's split_LU + peel_diag_crs,
+    // tests/test_gpu_kernels.py), for generated and for file inputs alike; the host versions of utilities/LU_factors.hpp
+    // remain for callers that hold host matrices
+    {
         bis_mat *Ls = nullptr, *Us = nullptr;
-        bis::check(bis_mat_split_strict(bis::ctx(), s->A->dev, &Ls, &Us, s->A_D, s->A_D_inv), "bis_mat_split_strict");
+        const bis_status st = bis_mat_split_strict(bis::ctx(), s->A->dev, &Ls, &Us, s->A_D, s->A_D_inv);
+        if (st == BIS_ERR_ZERO_DIAG || st == BIS_ERR_NO_DIAG) { fprintf(stderr, "%s\n", bis_last_error(bis::ctx())); exit(EXIT_FAILURE); }
+        bis::check(st, "bis_mat_split_strict");
         s->L_strict->adopt(Ls);
         s->U_strict->adopt(Us);
-    } else {
-        split_LU(s->A.get(), s->L.get(), s->L_strict.get(), s->U.get(), s->U_strict.get());
-        std::vector<double> D(N, 1.0), Dinv(N, 0.0);
-        peel_diag_crs(s->L.get(), D.data(), Dinv.data());
-        peel_diag_crs(s->U.get(), D.data(), Dinv.data());
-        to_device(s->A_D, D.data(), N);
-        to_device(s->A_D_inv, Dinv.data(), N);
-        s->L_strict->upload();
-        s->U_strict->upload();
     }
     if (s->preconditioner == PrecondType::ILU0) {
         // The reference's wired-in factor_ILU0_new needs the SMAX library (SURVEY.md

@@ -22,14 +22,14 @@ inline void multicolour_permutation(const MatrixCRS *A, std::vector<int> &perm, 
     // symmetrised adjacency (pattern of A + A^T) in CSR form
     std::vector<int> deg(n + 1, 0);
     for (int r = 0; r < n; ++r)
-        for (int k = A->row_ptr[r]; k < A->row_ptr[r + 1]; ++k) {
+        for (crs_index k = A->row_ptr[r]; k < A->row_ptr[r + 1]; ++k) {
             const int c = A->col[k];
             if (c != r) { ++deg[r + 1]; ++deg[c + 1]; }
         }
     for (int r = 0; r < n; ++r) deg[r + 1] += deg[r];
     std::vector<int> adj(deg[n]), fill(deg.begin(), deg.end() - 1);
     for (int r = 0; r < n; ++r)
-        for (int k = A->row_ptr[r]; k < A->row_ptr[r + 1]; ++k) {
+        for (crs_index k = A->row_ptr[r]; k < A->row_ptr[r + 1]; ++k) {
             const int c = A->col[k];
             if (c != r) { adj[fill[r]++] = c; adj[fill[c]++] = r; }
         }
@@ -56,7 +56,7 @@ inline void symmetric_adjacency(const MatrixCRS *A, std::vector<int> &ptr, std::
     const int n = A->n_rows;
     ptr.assign(n + 1, 0);
     for (int r = 0; r < n; ++r)
-        for (int k = A->row_ptr[r]; k < A->row_ptr[r + 1]; ++k) {
+        for (crs_index k = A->row_ptr[r]; k < A->row_ptr[r + 1]; ++k) {
             const int c = A->col[k];
             if (c != r) { ++ptr[r + 1]; ++ptr[c + 1]; }
         }
@@ -64,7 +64,7 @@ inline void symmetric_adjacency(const MatrixCRS *A, std::vector<int> &ptr, std::
     adj.resize(ptr[n]);
     std::vector<int> fill(ptr.begin(), ptr.end() - 1);
     for (int r = 0; r < n; ++r)
-        for (int k = A->row_ptr[r]; k < A->row_ptr[r + 1]; ++k) {
+        for (crs_index k = A->row_ptr[r]; k < A->row_ptr[r + 1]; ++k) {
             const int c = A->col[k];
             if (c != r) { adj[fill[r]++] = c; adj[fill[c]++] = r; }
         }
@@ -128,14 +128,14 @@ inline void permute_matrix(const MatrixCRS *A, const std::vector<int> &perm, con
     const int n = A->n_rows;
     B->free_host();
     B->n_rows = n; B->n_cols = A->n_cols; B->nnz = A->nnz;
-    B->row_ptr = new int[n + 1];
+    B->row_ptr = new crs_index[n + 1];
     B->col = new int[A->nnz ? A->nnz : 1];
     B->val = new double[A->nnz ? A->nnz : 1];
     B->row_ptr[0] = 0;
     for (int i = 0; i < n; ++i) B->row_ptr[i + 1] = B->row_ptr[i] + (A->row_ptr[perm[i] + 1] - A->row_ptr[perm[i]]);
     for (int i = 0; i < n; ++i) {
-        int p = B->row_ptr[i];
-        for (int k = A->row_ptr[perm[i]]; k < A->row_ptr[perm[i] + 1]; ++k) {
+        crs_index p = B->row_ptr[i];
+        for (crs_index k = A->row_ptr[perm[i]]; k < A->row_ptr[perm[i] + 1]; ++k) {
             B->col[p] = inv_perm[A->col[k]];
             B->val[p++] = A->val[k];
         }

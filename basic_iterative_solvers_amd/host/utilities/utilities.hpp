@@ -8,6 +8,8 @@
 // `-perm mc` applies the multi-colour reordering of utilities/permute.hpp.
 #pragma once
 
+#include <sys/stat.h>
+
 #include "../common.hpp"
 #include "../sparse_matrix.hpp"
 
@@ -112,39 +114,58 @@ inline void print_timers(Args *cli_args, Timers *timers) {
 }
 
 inline void convert_coo_to_crs(MatrixCOO *coo, MatrixCRS *crs) {
-    crs->n_rows = coo->n_rows; crs->n_cols = coo->n_cols; crs->nnz = coo->nnz;
-    crs->row_ptr = new int[crs->n_rows + 1]();
+    crs->n_rows = (int)coo->n_rows; crs->n_cols = (int)coo->n_cols; crs->nnz = coo->nnz;
+    crs->row_ptr = new crs_index[crs->n_rows + 1]();
     crs->col = new int[crs->nnz ? crs->nnz : 1];
     crs->val = new double[crs->nnz ? crs->nnz : 1];
-    for (int k = 0; k < crs->nnz; ++k) { crs->col[k] = coo->J[k]; crs->val[k] = coo->values[k]; ++crs->row_ptr[coo->I[k] + 1]; }
+    for (crs_index k = 0; k < crs->nnz; ++k) { crs->col[k] = coo->J[k]; crs->val[k] = coo->values[k]; ++crs->row_ptr[coo->I[k] + 1]; }
     for (int r = 0; r < crs->n_rows; ++r) crs->row_ptr[r + 1] += crs->row_ptr[r];
     if (crs->row_ptr[crs->n_rows] != crs->nnz) { printf("ERROR: converting to CRS.\n"); exit(1); }
 }
 
-// Binary CRS cache of a parsed .mtx input: header {magic, n_rows, n_cols, nnz}
-// as int64, then row_ptr (int32[n_rows+1]), col (int32[nnz]), val (double[nnz]) exactly as
-// convert_coo_to_crs produced them, so a cached run sees the same matrix bit for bit.
-inline bool read_crs_cache(const std::string &path, MatrixCRS *A) {
+// Binary CRS cache of a parsed .mtx input: header {magic, n_rows, n_cols, nnz, size and
+// modification time of the .mtx it was made from} as int64, then row_ptr (int64[n_rows+1]), col (int32[nnz]),
+// val (double[nnz]) exactly as convert_coo_to_crs produced them, so a cached run sees the same matrix bit for bit.
+// A cache that does not belong to the named .mtx (other size / time stamp), is truncated, or whose structure is
+// not a CRS (row_ptr not monotone from 0 to nnz, column out of range) is ignored and rewritten.
+inline bool source_stamp(const std::string &mtx, long long &size, long long &mtime) {
+    struct stat st;
+    if (stat(mtx.c_str(), &st) != 0) return false;
+    size = (long long)st.st_size; mtime = (long long)st.st_mtime;
+    return true;
+}
+inline bool read_crs_cache(const std::string &path, const std::string &mtx, MatrixCRS *A) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    long long h[4] = {0, 0, 0, 0};
-    bool ok = fread(h, sizeof(long long), 4, f) == 4 && h[0] == 0x4253435253ll && h[1] >= 0 && h[3] >= 0;
+    long long h[6] = {0, 0, 0, 0, 0, 0}, sz = 0, mt = 0;
+    bool ok = fread(h, sizeof(long long), 6, f) == 6 && h[0] == 0x4253435232ll && source_stamp(mtx, sz, mt) && h[4] == sz && h[5] == mt &&
+              h[1] >= 0 && h[1] < INT32_MAX && h[2] == h[1] && h[3] >= 0;
+    if (ok) { // the payload must be exactly what the header promises
+        const long long want = 48 + 8 * (h[1] + 1) + 12 * h[3];
+        struct stat st;
+        ok = stat(path.c_str(), &st) == 0 && (long long)st.st_size == want;
+    }
     if (ok) {
         MatrixCRS tmp((std::size_t)h[1], (std::size_t)h[2], (std::size_t)h[3]);
-        ok = fread(tmp.row_ptr, sizeof(int), (size_t)h[1] + 1, f) == (size_t)h[1] + 1 &&
+        ok = fread(tmp.row_ptr, sizeof(crs_index), (size_t)h[1] + 1, f) == (size_t)h[1] + 1 &&
              fread(tmp.col, sizeof(int), (size_t)h[3], f) == (size_t)h[3] &&
              fread(tmp.val, sizeof(double), (size_t)h[3], f) == (size_t)h[3];
+        ok = ok && tmp.row_ptr[0] == 0 && tmp.row_ptr[h[1]] == h[3];
+        for (long long r = 0; ok && r < h[1]; ++r) ok = tmp.row_ptr[r] <= tmp.row_ptr[r + 1];
+        for (long long k = 0; ok && k < h[3]; ++k) ok = tmp.col[k] >= 0 && tmp.col[k] < h[2];
         if (ok) *A = tmp;
     }
     fclose(f);
     return ok;
 }
-inline void write_crs_cache(const std::string &path, const MatrixCRS *A) {
+inline void write_crs_cache(const std::string &path, const std::string &mtx, const MatrixCRS *A) {
+    long long sz = 0, mt = 0;
+    if (!source_stamp(mtx, sz, mt)) return;
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) { fprintf(stderr, "WARNING: cannot write the CRS cache %s\n", path.c_str()); return; }
-    const long long h[4] = {0x4253435253ll, A->n_rows, A->n_cols, A->nnz};
-    fwrite(h, sizeof(long long), 4, f);
-    fwrite(A->row_ptr, sizeof(int), (size_t)A->n_rows + 1, f);
+    const long long h[6] = {0x4253435232ll, A->n_rows, A->n_cols, A->nnz, sz, mt};
+    fwrite(h, sizeof(long long), 6, f);
+    fwrite(A->row_ptr, sizeof(crs_index), (size_t)A->n_rows + 1, f);
     fwrite(A->col, sizeof(int), (size_t)A->nnz, f);
     fwrite(A->val, sizeof(double), (size_t)A->nnz, f);
     fclose(f);

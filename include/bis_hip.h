@@ -102,7 +102,9 @@ BIS_API bis_status bis_vec_download(bis_ctx *ctx, double *dst_host,
 /* MatrixCRS(n_rows, n_cols, nnz) + array fill (sparse_matrix.hpp:76-89) and
  * SMAX register_A (smax_helpers.hpp:10-11): uploads host CRS arrays exactly
  * as given (int32 row_ptr/col, fp64 val, arbitrary column order inside a
- * row) and builds the row-block metadata the SpMV kernel uses. */
+ * row) and builds the row-block metadata the SpMV kernel uses.  The structure
+ * is checked on the device (row_ptr monotone from 0 to nnz, columns inside
+ * [0, n_cols)): BIS_ERR_INVALID instead of a memory fault later. */
 BIS_API bis_status bis_mat_create(bis_ctx *ctx, int64_t n_rows, int64_t n_cols,
                                   int64_t nnz, const int32_t *row_ptr,
                                   const int32_t *col, const double *val,
@@ -128,7 +130,9 @@ BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
  * streamed arrays (values and column stream) up to max_trials times, times the SpMV
  * on each copy and keeps the fastest; the rejected copies are held until the end so
  * that every trial sees different memory.  Transient memory: up to max_trials copies.
- * Not for row views; call before views of A are made (bis_dist_create).
+ * Not for row views; call it before views of A are made (bis_dist_create) and
+ * before the first triangular solve on A (its plan caches views): refused
+ * with BIS_ERR_INVALID afterwards.
  * first_ms / best_ms (optional): SpMV time before and after. */
 BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_trials,
                                           double *first_ms, double *best_ms);
