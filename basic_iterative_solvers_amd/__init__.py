@@ -203,6 +203,12 @@ class Context:
         self.check(self.lib.bis_mat_diag(self.h, A.h, _i64(row_offset), C.c_void_p(D.ptr), C.c_void_p(Dinv.ptr)))
         return D, Dinv
 
+    def diag_block(self, A, row_offset=0):
+        """Square diagonal block of a row block with global columns (bis_mat_diag_block)."""
+        h = C.c_void_p()
+        self.check(self.lib.bis_mat_diag_block(self.h, A.h, _i64(row_offset), C.byref(h)))
+        return Mat(self, h)
+
     def ilu0(self, A, pivot_tol=1e-8, pivot_repl=1e-4):
         n = A.n_rows
         L_D, U_D = self.alloc(n), self.alloc(n)
@@ -363,6 +369,15 @@ class CG:
         self.h = C.c_void_p()
         ctx.check(ctx.lib.bis_cg_create(ctx.h, A.h, C.c_void_p(A_D.ptr) if A_D else C.c_void_p(),
                                         C.c_void_p(b.ptr), C.c_void_p(x.ptr), C.byref(self.h)))
+
+    def set_preconditioner(self, pc, Ls=None, Us=None, A_D=None, A_D_inv=None, L_D=None, U_D=None, outer=1, inner=0):
+        def p(v):
+            return C.c_void_p(v.ptr) if v is not None else C.c_void_p()
+        self._keep = (Ls, Us, A_D, A_D_inv, L_D, U_D)
+        self.ctx.check(self.ctx.lib.bis_cg_set_preconditioner(
+            self.ctx.h, self.h, C.c_int(PC[pc] if isinstance(pc, str) else pc),
+            Ls.h if Ls is not None else C.c_void_p(), Us.h if Us is not None else C.c_void_p(),
+            p(A_D), p(A_D_inv), p(L_D), p(U_D), C.c_int(outer), C.c_int(inner)))
 
     def init(self, tol):
         r0 = C.c_double()

@@ -48,6 +48,12 @@ struct bis_cg {
     int hist_cap = 0;
     int enqueued = 0;
     unsigned *counters = nullptr; // device: arrival tickets of the last-arriver reductions ([0] pap, [1] pass B)
+    // general preconditioner (bis_cg_set_preconditioner): z = M^-1 r through bis_apply_preconditioner
+    int pc = -1;
+    const bis_mat *pcL = nullptr, *pcU = nullptr;
+    const double *pcAD = nullptr, *pcADinv = nullptr, *pcLD = nullptr, *pcUD = nullptr;
+    double *pc_work = nullptr;
+    int pc_outer = 1, pc_inner = 0;
 };
 
 namespace {
@@ -281,6 +287,26 @@ bis_status bis_dist_cg_create(bis_ctx *ctx, bis_dist *d, const double *A_D, cons
     return cg_create_common(ctx, d, nullptr, A_D, b, x, out);
 }
 
+bis_status bis_cg_set_preconditioner(bis_ctx *ctx, bis_cg *cg, int precond_type, const bis_mat *L_strict, const bis_mat *U_strict,
+                                     const double *A_D, const double *A_D_inv, const double *L_D, const double *U_D,
+                                     int outer_iters, int inner_iters) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, cg && precond_type >= BIS_PC_NONE && precond_type <= BIS_PC_ILU0 && outer_iters >= 1 && inner_iters >= 0,
+                "bis_cg_set_preconditioner: bad arguments");
+    BIS_REQUIRE(ctx, cg->enqueued == 0, "bis_cg_set_preconditioner: call it before bis_cg_init / bis_cg_iterate");
+    if (cg->z == cg->r) { // z aliased r (no preconditioner at creation): it needs its own storage now
+        cg->z = nullptr;
+        bis_status st = bis_vec_alloc(ctx, cg->n, &cg->z);
+        if (st != BIS_OK) { cg->z = cg->r; return st; }
+    }
+    if (!cg->pc_work) { bis_status st = bis_vec_alloc(ctx, cg->n, &cg->pc_work); if (st != BIS_OK) return st; }
+    cg->pc = precond_type;
+    cg->pcL = L_strict; cg->pcU = U_strict;
+    cg->pcAD = A_D; cg->pcADinv = A_D_inv; cg->pcLD = L_D; cg->pcUD = U_D;
+    cg->pc_outer = outer_iters; cg->pc_inner = inner_iters;
+    return BIS_OK;
+}
+
 bis_status bis_cg_destroy(bis_ctx *ctx, bis_cg *cg) {
     BIS_CTX_OK(ctx);
     if (!cg) return BIS_OK;
@@ -294,6 +320,7 @@ bis_status bis_cg_destroy(bis_ctx *ctx, bis_cg *cg) {
     hipFree(cg->hist);
     hipFree(cg->flags);
     hipFree(cg->counters);
+    hipFree(cg->pc_work);
     delete cg;
     return BIS_OK;
 }
@@ -312,7 +339,10 @@ bis_status bis_cg_init(bis_ctx *ctx, bis_cg *cg, double tol, double *r0_norm_hos
     } else {
         st = bis_compute_residual(ctx, cg->A, cg->x, cg->b, cg->r, cg->tmp);
     }
-    if (st == BIS_OK && cg->A_D) st = bis_elemwise_div_vectors(ctx, cg->z, cg->r, cg->A_D, n, 1.0);
+    if (st == BIS_OK && cg->pc >= 0)
+        st = bis_apply_preconditioner(ctx, cg->pc, n, cg->pcL, cg->pcU, cg->pcAD, cg->pcADinv, cg->pcLD, cg->pcUD, cg->z, cg->r, cg->tmp,
+                                      cg->pc_work, cg->pc_outer, cg->pc_inner);
+    else if (st == BIS_OK && cg->A_D) st = bis_elemwise_div_vectors(ctx, cg->z, cg->r, cg->A_D, n, 1.0);
     if (st == BIS_OK) st = bis_copy_vector(ctx, cg->p, cg->z, n);
     if (cg->dist) {
         if (st == BIS_OK) st = bis_dist_dot(ctx, cg->dist, cg->r, cg->z, ctx->scalars_dev + 8, &rz);
@@ -356,9 +386,18 @@ static bis_status cg_enqueue_iteration(bis_ctx *ctx, bis_cg *cg, int g, int it) 
     hipLaunchKernelGGL((cg_update_kernel<J, D>), dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags,    \
                        cg->tmp, cg->A_D, cg->r, cg->z, ctx->partials, (size_t)kMaxReduceBlocks,              \
                        cg->counters + 1, cg->hist, cg->hist_cap)
-    if (cg->dist) { if (cg->A_D) BIS_CG_UPDATE(true, true); else BIS_CG_UPDATE(false, true); }
+    if (cg->pc >= 0) BIS_CG_UPDATE(false, true); // r update and (r,r) only; z and (r,z) follow below
+    else if (cg->dist) { if (cg->A_D) BIS_CG_UPDATE(true, true); else BIS_CG_UPDATE(false, true); }
     else { if (cg->A_D) BIS_CG_UPDATE(true, false); else BIS_CG_UPDATE(false, false); }
 #undef BIS_CG_UPDATE
+    if (cg->pc >= 0) { // general preconditioner: z = M^-1 r (triangular sweeps ...), then (r,z) with the stream-ordered dot
+        st = bis_apply_preconditioner(ctx, cg->pc, n, cg->pcL, cg->pcU, cg->pcAD, cg->pcADinv, cg->pcLD, cg->pcUD, cg->z, cg->r, cg->tmp,
+                                      cg->pc_work, cg->pc_outer, cg->pc_inner);
+        if (st == BIS_OK) st = bis_dot_dev(ctx, cg->r, cg->z, n, cg->sc + S_RZ_NEW);
+        if (st != BIS_OK) return st;
+        if (!cg->dist)
+            hipLaunchKernelGGL(cg_book_kernel, dim3(1), dim3(64), 0, ctx->stream, cg->sc, cg->flags, cg->hist, cg->hist_cap);
+    }
     if (cg->dist) {
         st = bis_dist_allreduce(ctx, cg->dist, cg->sc + S_RZ_NEW, 2); // {(r,z),(r,r)} batched
         if (st != BIS_OK) return st;

@@ -193,6 +193,53 @@ __global__ __launch_bounds__(256) void diag_kernel(const RP *__restrict__ row_pt
     if (!have) atomicMin(status, ((unsigned long long)(g + 1) << 1) | 1ull);
 }
 
+// entries of the diagonal block (row_offset <= col < row_offset + n_rows) per row; per-block sums
+template <typename RP>
+__global__ __launch_bounds__(256) void block_count_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col, int64_t n_rows,
+                                                          int64_t row_offset, int64_t *__restrict__ blk) {
+    __shared__ double lds[4];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int cnt = 0;
+    if (r < n_rows)
+        for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) {
+            const int64_t c = (int64_t)col[k] - row_offset;
+            cnt += (c >= 0 && c < n_rows);
+        }
+    const double s = block_sum<256>((double)cnt, lds);
+    if (threadIdx.x == 0) blk[blockIdx.x] = (int64_t)s;
+}
+template <typename RP, typename RPO>
+__global__ __launch_bounds__(256) void block_fill_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                         const double *__restrict__ val, int64_t n_rows, int64_t row_offset,
+                                                         const int64_t *__restrict__ blk, RPO *__restrict__ rpB, int32_t *__restrict__ colB,
+                                                         double *__restrict__ valB) {
+    __shared__ int64_t sc[256];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int cnt = 0;
+    if (r < n_rows)
+        for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) {
+            const int64_t c = (int64_t)col[k] - row_offset;
+            cnt += (c >= 0 && c < n_rows);
+        }
+    sc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int64_t v = 0;
+        if ((int)threadIdx.x >= off) v = sc[threadIdx.x - off];
+        __syncthreads();
+        sc[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (r >= n_rows) return;
+    int64_t p = blk[blockIdx.x] + sc[threadIdx.x] - cnt;
+    rpB[r] = (RPO)p;
+    if (r == n_rows - 1) rpB[n_rows] = (RPO)(p + cnt);
+    for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) {
+        const int64_t c = (int64_t)col[k] - row_offset;
+        if (c >= 0 && c < n_rows) { colB[p] = (int32_t)c; valB[p++] = val[k]; }
+    }
+}
+
 // Device version of bis_halo_plan: same outputs (sorted distinct remote columns, per-owner counts,
 // longest interior row run) from the remote entries and boundary rows alone -- a z-slab of HPCG-512 / 8
 // ships 2 x 512^2 x 9 column indices and 2 x 512^2 row indices instead of 1.8 GB of CRS structure.
@@ -385,6 +432,57 @@ bis_status bis_mat_diag(bis_ctx *ctx, const bis_mat *A, int64_t row_offset, doub
         return missing ? BIS_ERR_NO_DIAG : BIS_ERR_ZERO_DIAG;
     }
     return BIS_OK;
+}
+
+} // extern "C"
+
+// The diagonal block of a row block with GLOBAL column indices: the entries with row_offset <= col < row_offset +
+// n_rows, columns renumbered to [0, n_rows), order inside a row kept.
+template <typename RP>
+static bis_status diag_block_t(bis_ctx *ctx, const bis_mat *A, int64_t row_offset, bis_mat **out) {
+    const int64_t n = A->n_rows;
+    const int n_blk = (int)((n + 255) / 256);
+    int64_t *blk = nullptr;
+    BIS_HIP_CHECK(ctx, hipMalloc(&blk, sizeof(int64_t) * (size_t)(2 * n_blk + 4)));
+    int64_t *blk_ent = blk, *dummy = blk + n_blk, *tot = blk + 2 * n_blk;
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(blk, 0, sizeof(int64_t) * (size_t)(2 * n_blk + 4), ctx->stream));
+    if (n_blk) {
+        hipLaunchKernelGGL((block_count_kernel<RP>), dim3(n_blk), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, n, row_offset, blk_ent);
+        hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, blk_ent, dummy, n_blk, tot);
+    }
+    int64_t h_tot[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(h_tot, tot, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { hipFree(blk); ctx->err = "bis_mat_diag_block: count pass failed"; return BIS_ERR_HIP; }
+    bis_mat *B = nullptr;
+    bis_status st = bis_mat_alloc(ctx, n, n, h_tot[0], bis_want_rp64(h_tot[0]), &B);
+    if (st != BIS_OK) { hipFree(blk); return st; }
+    if (n_blk) {
+        if (B->rp64)
+            hipLaunchKernelGGL((block_fill_kernel<RP, int64_t>), dim3(n_blk), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->val, n,
+                               row_offset, blk_ent, (int64_t *)B->row_ptr, B->col, B->val);
+        else
+            hipLaunchKernelGGL((block_fill_kernel<RP, int32_t>), dim3(n_blk), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->val, n,
+                               row_offset, blk_ent, (int32_t *)B->row_ptr, B->col, B->val);
+    } else {
+        hipMemsetAsync(B->row_ptr, 0, B->rp64 ? 8 : 4, ctx->stream);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(blk);
+    if (e != hipSuccess) { bis_mat_destroy(ctx, B); ctx->err = "bis_mat_diag_block: fill pass failed"; return BIS_ERR_HIP; }
+    st = bis_mat_finalize(ctx, B);
+    if (st != BIS_OK) { bis_mat_destroy(ctx, B); return st; }
+    *out = B;
+    return BIS_OK;
+}
+
+extern "C" {
+
+bis_status bis_mat_diag_block(bis_ctx *ctx, const bis_mat *A_local, int64_t row_offset, bis_mat **block) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A_local && block && row_offset >= 0, "bis_mat_diag_block: bad arguments");
+    return A_local->rp64 ? diag_block_t<int64_t>(ctx, A_local, row_offset, block) : diag_block_t<int32_t>(ctx, A_local, row_offset, block);
 }
 
 bis_status bis_dist_create(bis_ctx *ctx, bis_mat *A, int rank, int n_ranks, const int64_t *row_starts,

@@ -374,6 +374,16 @@ BIS_API bis_status bis_cg_create(bis_ctx *ctx, const bis_mat *A,
                                  const double *A_D, const double *b, double *x,
                                  bis_cg **out);
 BIS_API bis_status bis_cg_destroy(bis_ctx *ctx, bis_cg *cg);
+/* General preconditioner for the fused CG (single GPU or distributed handle):
+ * z = M^-1 r through bis_apply_preconditioner (kernels.hpp:336-414) with the
+ * given operands (all LOCAL to this rank), instead of None / Jacobi.  Pass B
+ * then updates r and (r,r) only; the sweep(s) and a stream-ordered (r,z) follow;
+ * everything stays on the device as before.  Call before bis_cg_init. */
+BIS_API bis_status bis_cg_set_preconditioner(bis_ctx *ctx, bis_cg *cg, int precond_type,
+                                             const bis_mat *L_strict, const bis_mat *U_strict,
+                                             const double *A_D, const double *A_D_inv,
+                                             const double *L_D, const double *U_D,
+                                             int outer_iters, int inner_iters);
 /* init_residual (cg.hpp:100-118) + init_stopping_criteria (solver.hpp:173):
  * r0 = b - A x0, z0 = M^-1 r0, p0 = z0; returns ||r0||_2 (blocking). */
 BIS_API bis_status bis_cg_init(bis_ctx *ctx, bis_cg *cg, double tol,
@@ -433,6 +443,16 @@ typedef struct bis_dist bis_dist;
  * Jacobi preconditioner of its rows (config 3: -cg -p j across GPUs). */
 BIS_API bis_status bis_mat_diag(bis_ctx *ctx, const bis_mat *A_local,
                                 int64_t row_offset, double *D, double *D_inv);
+/* The square diagonal block of a row block (entries with row_offset <= col <
+ * row_offset + n_rows, columns renumbered to local, order inside a row kept).
+ * Triangular sweeps do not cross ranks (a sequential wavefront, SURVEY.md
+ * section 8e): a row-partitioned solve preconditions with Gauss-Seidel /
+ * SGS / ILU(0) of THIS block on every rank -- block-Jacobi of the sweeps, a
+ * different preconditioner from the single-GPU one (its own parity target:
+ * tests/dist_worker.py).  Feed it to bis_mat_split_strict / bis_mat_ilu0 and
+ * hand the factors to bis_cg_set_preconditioner. */
+BIS_API bis_status bis_mat_diag_block(bis_ctx *ctx, const bis_mat *A_local,
+                                      int64_t row_offset, bis_mat **block);
 
 /* Transport, provided by the launcher or by bis_dist_use_rccl.  Buffers are
  * DEVICE pointers; the operation must be ordered on `stream` (a hipStream_t).

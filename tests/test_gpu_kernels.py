@@ -836,3 +836,35 @@ def test_device_bfs_refuses_unsymmetric_patterns_and_bad_permutations(ctx):
         ctx.bfs_order(dA)
     with pytest.raises(BisError, match="not a permutation"):
         ctx.permute(dA, np.array([0, 0, 2], dtype=np.int32))
+
+
+_PCG_KEYS = sorted(k for k in _H if k.split("|")[1] == "cg" and k.split("|")[2] in ("sgs", "ilu0", "s2st", "j")
+                   and "num_scale" not in k)
+
+
+@pytest.mark.parametrize("key", _PCG_KEYS)
+def test_fused_cg_general_preconditioner_vs_reference(ctx, key):
+    """bis_cg_set_preconditioner: the fused device CG with z = M^-1 r through bis_apply_preconditioner (triangular
+    sweeps of SGS / ILU(0), the two-stage form, Jacobi) against the reference's -cg -p ... residual tables."""
+    e = _H[key]
+    name, solver, pc, kw = parse_hist_key(key)
+    g = load_golden(name)
+    A = crs_of(g, "A")
+    n = A.n_rows
+    dA = ctx.matrix(A)
+    b, x = ctx.upload(np.full(n, 1.0)), ctx.upload(np.full(n, 0.1))
+    ones = ctx.upload(np.ones(n))
+    if pc == "ilu0":
+        Ls, L_D, Us, U_D = ctx.ilu0(dA)
+        args = dict(Ls=Ls, Us=Us, A_D=ones, A_D_inv=ones, L_D=L_D, U_D=U_D)
+    else:
+        Ls, Us, D, Dinv = ctx.split_strict(dA)
+        args = dict(Ls=Ls, Us=Us, A_D=D, A_D_inv=Dinv, L_D=ones, U_D=ones)
+    cg = ctx.cg(dA, b, x)
+    cg.set_preconditioner(pc, **args)
+    r0 = cg.init(1e-14)
+    assert abs(r0 - e["hist"][0]) <= 1e-13 * e["hist"][0]
+    cg.iterate(1000)
+    iters, conv, hist = cg.status()
+    check_history(dict(hist=hist, iters=iters, converged=conv), e, "cg")
+    cg.free()
