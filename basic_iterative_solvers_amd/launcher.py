@@ -79,17 +79,26 @@ def torch_comm_ops(td, torch, n_ranks, rank, group=None):
     def wrap(ptr, n):
         return torch.as_tensor(_DevArray(ptr, n), device="cuda")
 
+    import os
+    trace = os.environ.get("BIS_DIST_TRACE") == "1"
+
     def allreduce(user, stream, buf, count):
+        if trace:
+            print(f"rank {rank}: allreduce({count}) enter", flush=True)
         try:
             with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
                 t = wrap(buf, count)
                 td.all_reduce(t, group=group)
+            if trace:
+                print(f"rank {rank}: allreduce({count}) done", flush=True)
             return 0
         except Exception as ex:  # noqa
             print("allreduce callback failed:", ex, flush=True)
             return 1
 
     def exchange(user, stream, sendbuf, send_counts, recvbuf, recv_counts, n):
+        if trace:
+            print(f"rank {rank}: exchange enter", flush=True)
         try:
             with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
                 torch.cuda.current_stream().synchronize()
@@ -106,6 +115,8 @@ def torch_comm_ops(td, torch, n_ranks, rank, group=None):
                     for r in td.batch_isend_irecv(ops):
                         r.wait()
                 torch.cuda.current_stream().synchronize()
+            if trace:
+                print(f"rank {rank}: exchange done", flush=True)
             return 0
         except Exception as ex:  # noqa
             print("exchange callback failed:", ex, flush=True)
