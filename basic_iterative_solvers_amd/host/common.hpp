@@ -83,6 +83,7 @@ struct Args {
     std::string dump_x;             // -dump-x FILE: write x* (natural row order, also after -perm)
     std::string crs_cache;          // -cache FILE: binary CRS next to a .mtx input (read if present, else written)
     bool perm_host = false;         // -perm-host: colour and permute on the host (fallback path)
+    bool trsv_tiled = false;        // -trsv tiled: natural-order sweeps with the tiled kernel (plan built on the host at the first sweep)
     int device = 0;
 };
 

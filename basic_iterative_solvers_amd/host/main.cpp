@@ -49,6 +49,7 @@ int main(int argc, char *argv[]) {
     Args cli_args;
     parse_cli(&cli_args, argc, argv);
     bis::init(cli_args.device);
+    if (cli_args.trsv_tiled) bis_set_option("trsv_tiled", 1);
     TIME(&timers, "total", run(&cli_args, &timers))
     print_timers(&cli_args, &timers);
     bis::shutdown();

@@ -61,6 +61,7 @@ inline void parse_cli(Args *a, int argc, char *argv[]) {
         else if (arg == "-rl" && i + 1 < argc) a->restart_length = atoi(argv[++i]);
         else if (arg == "-unfused") a->unfused = true;
         else if (arg == "-hostscalars") a->host_scalars = true;
+        else if (arg == "-trsv" && i + 1 < argc) a->trsv_tiled = std::string(argv[++i]) == "tiled";
         else if (arg == "-perm" && i + 1 < argc) a->perm_mode = argv[++i];
         else if (arg == "-dump-perm" && i + 1 < argc) a->dump_perm = argv[++i];
         else if (arg == "-dump-x" && i + 1 < argc) a->dump_x = argv[++i];
