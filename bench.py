@@ -24,6 +24,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# the CPUs this process may use, read before any OpenMP runtime binds the main thread to its first place
+try:
+    CPUS_ALLOWED = len(os.sched_getaffinity(0))
+except Exception:
+    CPUS_ALLOWED = None
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 
 
@@ -54,10 +60,7 @@ def parse():
 def host_topology():
     """Sockets / physical cores / logical CPUs of this box and the CPUs this process may run on."""
     topo = {"logical_cpus": os.cpu_count()}
-    try:
-        topo["cpus_allowed"] = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    topo["cpus_allowed"] = CPUS_ALLOWED
     try:
         phys, socks, model = set(), set(), None
         pid = cid = None
