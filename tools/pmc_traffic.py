@@ -29,7 +29,8 @@ def main():
     vec_kib = 8 * N / 1024
     # calibration: FETCH_SIZE (KiB) vs the true read bytes of 16 B/lane streaming kernels
     cal = {}
-    for k, n_read, n_write in (("cg_p_update_kernel", 2, 1), ("cg_update_kernel", 4, 2)):
+    # round-2 schedule (no preconditioner): pass C reads z (= r), p, x and writes x, p; pass B reads tmp, r and writes r
+    for k, n_read, n_write in (("cg_p_update_kernel", 3, 2), ("cg_update_kernel", 2, 1)):
         cal[k] = dict(fetch_factor=n_read * vec_kib / fetch[(k, "FETCH_SIZE")],
                       write_factor=n_write * vec_kib / write[(k, "WRITE_SIZE")])
     ff = sum(c["fetch_factor"] for c in cal.values()) / len(cal)
