@@ -224,6 +224,7 @@ bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot
     bis_mat *W = nullptr;
     bis_status st = bis_mat_alloc(ctx, n, A->n_cols, A->nnz, A->rp64, &W);
     if (st != BIS_OK) return st;
+    for (int i = 0; i < 4; ++i) W->grid[i] = A->grid[i]; // the factors inherit it through the split
     int64_t *dpos = nullptr, *ustart = nullptr;
     auto cleanup = [&](bis_status rc) {
         hipFree(dpos);

@@ -80,6 +80,7 @@ struct bis_options {
     int trsv_tiled = -1;    // natural-order sweeps: 1 = tiled sweep (bis_trsv_tiled.hip; opt-in: its plan is built on the host), else level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
+    int trsv_tile_edge = -1; // grid-hinted matrices: edge of the cubic tiles in nodes (default 16; 0 = interval tiles of the natural order)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
     int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes
 };
@@ -129,6 +130,9 @@ struct bis_mat {
     int chunk_nnz = 0;        // nnz budget per block used to build blk_row
     int max_row_nnz = 0;
     int64_t max_block_nnz = 0;
+    // structured-grid hint (generators, bis_mat_set_grid_hint): row = ((z*ny + y)*nx + x)*dof + d; 0 = none.
+    // Inherited by the strict triangles and the ILU(0) factors; the tiled sweep cuts its tiles in all grid directions with it.
+    int64_t grid[4] = {0, 0, 0, 0};
     // triangular-solve plans (built lazily)
     bis_trsv_plan *plan_fwd = nullptr;
     bis_trsv_plan *plan_bwd = nullptr;

@@ -660,6 +660,13 @@ BIS_API bis_status bis_mat_debug_ptrs(const bis_mat *A, void **row_ptr, void **c
 
 int bis_mat_rp_width(const bis_mat *A) { return A ? (A->rp64 ? 8 : 4) : 0; }
 
+bis_status bis_mat_set_grid_hint(bis_mat *A, int64_t nx, int64_t ny, int64_t nz, int dof) {
+    if (!A) return BIS_ERR_INVALID;
+    if (nx <= 0 || ny <= 0 || nz <= 0 || dof <= 0 || nx * ny * nz * dof != A->n_rows) return BIS_ERR_INVALID;
+    A->grid[0] = nx; A->grid[1] = ny; A->grid[2] = nz; A->grid[3] = dof;
+    return BIS_OK;
+}
+
 bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz) {
     if (!A) return BIS_ERR_INVALID;
     if (n_rows) *n_rows = A->n_rows;
@@ -715,6 +722,7 @@ bis_status bis_mat_gen_hpcg(bis_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, in
         hipLaunchKernelGGL(gen_hpcg_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, nx, ny,
                            nz, row0, row1, base, (int32_t *)A->row_ptr, A->col, A->val);
     if (hipGetLastError() != hipSuccess) { bis_mat_destroy(ctx, A); ctx->err = "gen_hpcg launch failed"; return BIS_ERR_HIP; }
+    if (row0 == 0 && row1 == N) { A->grid[0] = nx; A->grid[1] = ny; A->grid[2] = nz; A->grid[3] = 1; }
     st = bis_mat_finalize(ctx, A);
     if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
     *out = A;
@@ -740,6 +748,7 @@ bis_status bis_mat_gen_anderson(bis_ctx *ctx, int64_t L, double t, double W, dou
         hipLaunchKernelGGL(gen_anderson_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, L, t,
                            W, shift, seed, row0, row1, (int32_t *)A->row_ptr, A->col, A->val);
     if (hipGetLastError() != hipSuccess) { bis_mat_destroy(ctx, A); ctx->err = "gen_anderson launch failed"; return BIS_ERR_HIP; }
+    if (row0 == 0 && row1 == N) { A->grid[0] = L; A->grid[1] = L; A->grid[2] = L; A->grid[3] = 1; }
     st = bis_mat_finalize(ctx, A);
     if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
     *out = A;
@@ -787,6 +796,7 @@ bis_status bis_mat_gen_fem(bis_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(blk);
     if (e != hipSuccess) { bis_mat_destroy(ctx, A); ctx->err = "gen_fem launch failed"; return BIS_ERR_HIP; }
+    if (row0 == 0 && row1 == N) { A->grid[0] = nx; A->grid[1] = ny; A->grid[2] = nz; A->grid[3] = 3; }
     st = bis_mat_finalize(ctx, A);
     if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }
     *out = A;
@@ -872,6 +882,7 @@ bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L
     st = bis_mat_finalize(ctx, Lm);
     if (st == BIS_OK) st = bis_mat_finalize(ctx, Um);
     if (st != BIS_OK) { bis_mat_destroy(ctx, Lm); bis_mat_destroy(ctx, Um); return st; }
+    for (int i = 0; i < 4; ++i) { Lm->grid[i] = A->grid[i]; Um->grid[i] = A->grid[i]; } // same row space
     *L_strict = Lm;
     *U_strict = Um;
     return BIS_OK;

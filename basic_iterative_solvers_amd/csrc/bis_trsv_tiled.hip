@@ -383,10 +383,8 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
 } // namespace
 
 // ---- plan (host analysis) ---------------------------------------------------------------------------
-// Input: the strictly triangular pattern on the host.  Processing order: ascending rows (forward) or
-// descending rows (backward) -- the reference's substitution order, always a linear extension.
-// Tiles: intervals of the processing order of up to max_rows rows, cut where the next tile's first row
-// reaches back farthest.
+// Input: the strictly triangular pattern on the host.  Output: the processing order, its tiles, and per tile the
+// steps, the repacked entries and the list of external operands.
 bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_tiled **out) {
     *out = nullptr;
     const int64_t n = T->n_rows;
@@ -395,29 +393,112 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     std::vector<int32_t> col((size_t)T->nnz);
     bis_status st = bis_mat_download(ctx, T, rp.data(), col.data(), nullptr);
     if (st != BIS_OK) return st;
-    auto row_at = [&](int64_t pos) { return backward ? n - 1 - pos : pos; };
-    auto pos_of = [&](int64_t row) { return backward ? n - 1 - row : row; };
     int max_len = 0;
     for (int64_t r = 0; r < n; ++r) max_len = std::max<int>(max_len, (int)(rp[r + 1] - rp[r]));
     if ((max_len + 3) / 4 > kRingQ / 2) return BIS_OK; // a single row must fit half the quad ring
+    // The processing order: ord[pos] = row, any linear extension of the dependency order (every operand of a row sits
+    // at an earlier position).  Default: the reference's substitution order (ascending rows forward, descending
+    // backward) cut into intervals.  With a grid hint: tiles that extend in ALL grid directions.
+    std::vector<int32_t> ord((size_t)n), pos_v((size_t)n);
+    std::vector<int64_t> tile_pos0;
+    bool grid_tiles = false;
+    const int edge = bis_opts().trsv_tile_edge >= 0 ? bis_opts().trsv_tile_edge : 16;
+    if (T->grid[0] > 0 && edge > 0 && T->grid[0] * T->grid[1] * T->grid[2] * T->grid[3] == n) {
+        // Skewed tile-major order.  Node coordinates are mirrored for the backward sweep, so that in both directions an
+        // operand has a SMALLER node (or the same node and a smaller unknown).  With x' = x + a y + b z, y' = y + c z,
+        // z' = z and the smallest skews a, b, c for which every operand offset has x' <= 0, y' <= 0, z' <= 0, the order
+        // (tile of (z', y', x'), then (z', y', x', unknown) inside the tile) is a linear extension: 7-point stencils need
+        // no skew, 27-point ones a = 1, b = 2, c = 1.  The order is verified below; if it is not one (a pattern the
+        // hint does not describe), the interval tiles of the natural order are used.
+        const int64_t nx = T->grid[0], ny = T->grid[1], nz = T->grid[2], dof = T->grid[3];
+        auto node_of = [&](int64_t row, int64_t &x, int64_t &y, int64_t &z, int64_t &d) {
+            d = row % dof;
+            const int64_t a0 = row / dof;
+            x = a0 % nx; y = (a0 / nx) % ny; z = a0 / (nx * ny);
+            if (backward) { x = nx - 1 - x; y = ny - 1 - y; z = nz - 1 - z; d = dof - 1 - d; }
+        };
+        // distinct operand offsets (sampled on every row: O(nnz), cheap next to the rest of the plan)
+        std::vector<int64_t> offs; // packed (dx, dy, dz)
+        {
+            std::vector<int64_t> seen;
+            for (int64_t r = 0; r < n; ++r) {
+                int64_t x, y, z, d;
+                node_of(r, x, y, z, d);
+                for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+                    int64_t cx, cy, cz, cd;
+                    node_of(col[k], cx, cy, cz, cd);
+                    const int64_t key = ((cz - z + nz) * (2 * ny + 1) + (cy - y + ny)) * (2 * nx + 1) + (cx - x + nx);
+                    if (seen.size() < 128 && std::find(seen.begin(), seen.end(), key) == seen.end()) seen.push_back(key);
+                }
+                if (seen.size() >= 128) break; // not a stencil: no grid tiles
+            }
+            offs.swap(seen);
+        }
+        int sa = -1, sb = -1, sc = -1;
+        if (offs.size() < 128) {
+            for (int tot = 0; tot <= 9 && sa < 0; ++tot)
+                for (int a2 = 0; a2 <= 3 && sa < 0; ++a2)
+                    for (int b2 = 0; b2 <= 3 && sa < 0; ++b2) {
+                        const int c2 = tot - a2 - b2;
+                        if (c2 < 0 || c2 > 3) continue;
+                        bool ok = true;
+                        for (int64_t key : offs) {
+                            const int64_t dx = key % (2 * nx + 1) - nx, dy = (key / (2 * nx + 1)) % (2 * ny + 1) - ny, dz = key / ((2 * nx + 1) * (2 * ny + 1)) - nz;
+                            if (dz > 0 || dy + c2 * dz > 0 || dx + a2 * dy + b2 * dz > 0) { ok = false; break; }
+                        }
+                        if (ok) { sa = a2; sb = b2; sc = c2; }
+                    }
+        }
+        if (sa >= 0) {
+            const int64_t NXs = (nx + sa * (ny - 1) + sb * (nz - 1) + edge - 1) / edge, NYs = (ny + sc * (nz - 1) + edge - 1) / edge;
+            std::vector<std::pair<uint64_t, int32_t>> keyed((size_t)n);
+            for (int64_t r = 0; r < n; ++r) {
+                int64_t x, y, z, d;
+                node_of(r, x, y, z, d);
+                const int64_t xs = x + sa * y + sb * z, ys = y + sc * z, zs = z;
+                const uint64_t tile = (uint64_t)(((zs / edge) * NYs + ys / edge) * NXs + xs / edge);
+                const uint64_t intra = (uint64_t)((((zs % edge) * edge + ys % edge) * edge + xs % edge) * dof + d);
+                keyed[(size_t)r] = {tile * (uint64_t)(edge * edge * edge * dof) + intra, (int32_t)r};
+            }
+            std::sort(keyed.begin(), keyed.end());
+            const uint64_t tile_vol = (uint64_t)(edge * edge * edge * dof);
+            bool fits = tile_vol <= (uint64_t)kMaxB;
+            for (int64_t p = 0; p < n; ++p) { ord[(size_t)p] = keyed[(size_t)p].second; pos_v[(size_t)keyed[(size_t)p].second] = (int32_t)p; }
+            // a linear extension?
+            bool valid = fits;
+            for (int64_t r = 0; r < n && valid; ++r)
+                for (int64_t k = rp[r]; k < rp[r + 1]; ++k)
+                    if (pos_v[(size_t)col[k]] >= pos_v[(size_t)r]) { valid = false; break; }
+            if (valid) {
+                tile_pos0.push_back(0);
+                for (int64_t p = 1; p < n; ++p)
+                    if (keyed[(size_t)p].first / tile_vol != keyed[(size_t)p - 1].first / tile_vol) tile_pos0.push_back(p);
+                tile_pos0.push_back(n);
+                grid_tiles = true;
+            }
+        }
+    }
+    if (!grid_tiles) {
+        for (int64_t p = 0; p < n; ++p) { const int64_t r = backward ? n - 1 - p : p; ord[(size_t)p] = (int32_t)r; pos_v[(size_t)r] = (int32_t)p; }
+    }
+    auto row_at = [&](int64_t pos) { return (int64_t)ord[(size_t)pos]; };
+    auto pos_of = [&](int64_t row) { return (int64_t)pos_v[(size_t)row]; };
     // measured (tools/trsv_ab.py): 7-point 256^3 1.46 ms at 8192 (1.65 at 4096, 1.83 at 16384); 27-point 128^3 1.18 ms at 1024, 1.24 at 2048, 1.86 at 8192
     const int max_rows = bis_opts().trsv_tile_rows > 0 ? std::min(bis_opts().trsv_tile_rows, kMaxB) : (max_len <= 8 ? 8192 : 2048);
-    // pass A: tile boundaries.  Within the second half of its allowed extent a tile is cut where the next tile's first
-    // row depends only on results its predecessor produces EARLY (small local level).  Cutting in the middle of a
-    // grid line would make every tile wait for the end of its predecessor and serialise the sweep (measured: 494 ms
-    // instead of 4 ms on the 256^3 7-point grid, 280 ms instead of 4 ms on the FEM-like input); cutting at the start
-    // of a grid line lets it start on the predecessor's early results.
-    std::vector<int64_t> tile_pos0{0};
-    {
-        // score of a cut at position c of the candidate tile [p0, p): the local level, within that tile, of the deepest
-        // operand of row c (0 if all its operands precede the tile) -- how late in its predecessor the next tile could start
+    // pass A (interval tiles of the natural order): tile boundaries.  Within the second half of its allowed extent a
+    // tile is cut where the next tile's first row depends only on results its predecessor produces EARLY (small local
+    // level).  Cutting in the middle of a grid line would make every tile wait for the end of its predecessor and
+    // serialise the sweep (measured: 494 ms instead of 4 ms on the 256^3 7-point grid); cutting at the start of a
+    // grid line lets it start on the predecessor's early results.
+    if (!grid_tiles) {
+        tile_pos0.push_back(0);
         std::vector<int> lv((size_t)max_rows + 1);
         for (int64_t p0 = 0; p0 < n;) {
             const int64_t p = std::min<int64_t>(n, p0 + max_rows);
             int64_t cut = p;
             if (p < n) {
                 const int m = (int)(p - p0);
-                for (int i = 0; i < m; ++i) {
+                for (int i = 0; i <= m; ++i) { // i == m: row p itself (the cut that keeps the whole extent)
                     const int64_t r = row_at(p0 + i);
                     int l = 0;
                     for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
@@ -425,15 +506,6 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                         if (q >= p0) l = std::max(l, lv[(size_t)(q - p0)] + 1);
                     }
                     lv[(size_t)i] = l;
-                }
-                {   // row p itself (the cut that keeps the whole extent)
-                    const int64_t r = row_at(p);
-                    int l = 0;
-                    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
-                        const int64_t q = pos_of(col[k]);
-                        if (q >= p0) l = std::max(l, lv[(size_t)(q - p0)] + 1);
-                    }
-                    lv[(size_t)m] = l;
                 }
                 const int half = std::max(1, m / 2);
                 int best = INT32_MAX;
@@ -583,10 +655,10 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     }
     if (getenv("BIS_TRSV_TILE_STATS"))
         fprintf(stderr, "tiled sptrsv plan (%s): %lld rows, %d tiles (largest %d rows), %lld steps (%.1f rows per step), %lld quads (%.2f x the entries), "
-                        "%lld external ordinals (%.2f per row), %lld in-tile operands beyond the ring\n", backward ? "backward" : "forward",
+                        "%lld external ordinals (%.2f per row), %lld in-tile operands beyond the ring%s\n", backward ? "backward" : "forward",
                 (long long)n, p->n_tiles, tile_rows_max, (long long)p->n_steps, (double)n / (double)std::max<int64_t>(p->n_steps, 1),
                 (long long)p->n_quads, 4.0 * (double)p->n_quads / (double)T->nnz, (long long)p->n_ext, (double)p->n_ext / (double)n,
-                (long long)n_demoted);
+                (long long)n_demoted, grid_tiles ? "; grid tiles" : "; interval tiles");
     *out = p;
     return BIS_OK;
 }

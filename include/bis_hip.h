@@ -122,6 +122,15 @@ BIS_API bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows,
  * bis_set_option("force_rp64", 1) was in effect when the matrix was made (the
  * tests run the 64-bit instantiations at small sizes that way). */
 BIS_API int bis_mat_rp_width(const bis_mat *A);
+/* Structured-grid hint: the rows are the unknowns of an nx x ny x nz grid, x
+ * fastest, dof unknowns per node (row = ((z*ny + y)*nx + x)*dof + d) -- e.g.
+ * an HPCG-n.mtx read from a file.  The generators set it themselves; strict
+ * triangles and ILU(0) factors inherit it.  Only the tiled triangular sweep
+ * uses it (tiles that extend in all grid directions); a hint that does not
+ * describe the matrix costs speed, never correctness (the tile order is
+ * verified against the dependencies, else the natural order is used). */
+BIS_API bis_status bis_mat_set_grid_hint(bis_mat *A, int64_t nx, int64_t ny,
+                                         int64_t nz, int dof);
 /* rebuild a matrix' row-block metadata after bis_set_option (tuning) */
 BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
 /* Placement tuning (setup, optional): WHERE in HBM the streamed arrays of a matrix

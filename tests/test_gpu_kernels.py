@@ -733,9 +733,11 @@ def test_sptrsv_wave_grid_is_capped_by_residency(ctx, oracle):
         ctx.set_option("trsv_grid", -1)
 
 
-@pytest.mark.parametrize("kind,size,rows", [("anderson", 40, -1), ("anderson", 40, 700), ("hpcg", 32, -1), ("hpcg", 32, 300),
-                                             ("fem", (14, 12, 10), -1), ("fem", (14, 12, 10), 100)])
-def test_tiled_sweep_bit_exact(ctx, oracle, kind, size, rows):
+@pytest.mark.parametrize("kind,size,rows,edge", [("anderson", 40, -1, 0), ("anderson", 40, 700, 0), ("hpcg", 32, -1, 0), ("hpcg", 32, 300, 0),
+                                                  ("fem", (14, 12, 10), -1, 0), ("fem", (14, 12, 10), 100, 0),
+                                                  ("anderson", 40, -1, -1), ("anderson", 40, -1, 5), ("hpcg", 32, -1, -1), ("hpcg", 32, -1, 6),
+                                                  ("fem", (14, 12, 10), -1, 4), ("fem", (14, 12, 10), -1, -1)])
+def test_tiled_sweep_bit_exact(ctx, oracle, kind, size, rows, edge):
     """The opt-in tiled natural-order sweep (`trsv_tiled`, bis_trsv_tiled.hip: tiles solved by one workgroup each,
     in-tile operands through LDS rings, external ones through a poller wave): same CRS-order fma chain per row as
     the reference's serial loop -> bit-exact against the fma oracle, forward and backward, also with x aliasing b
@@ -751,6 +753,7 @@ def test_tiled_sweep_bit_exact(ctx, oracle, kind, size, rows):
     b = np.random.default_rng(17).uniform(-1, 1, n)
     ctx.set_option("trsv_tiled", 1)
     ctx.set_option("trsv_tile_rows", rows)
+    ctx.set_option("trsv_tile_edge", edge)
     try:
         dLs, dUs, dD, dDinv = ctx.split_strict(dA)
         db, x = ctx.upload(b), ctx.alloc(n)
@@ -767,6 +770,7 @@ def test_tiled_sweep_bit_exact(ctx, oracle, kind, size, rows):
     finally:
         ctx.set_option("trsv_tiled", -1)
         ctx.set_option("trsv_tile_rows", -1)
+        ctx.set_option("trsv_tile_edge", -1)
 
 
 def _queue_order(A, rcm):
