@@ -451,12 +451,17 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
         }
         if (sa >= 0) {
             const int64_t NXs = (nx + sa * (ny - 1) + sb * (nz - 1) + edge - 1) / edge, NYs = (ny + sc * (nz - 1) + edge - 1) / edge;
+            const uint64_t n_lex = (uint64_t)(((nz + edge - 1) / edge) * NYs * NXs);
             std::vector<std::pair<uint64_t, int32_t>> keyed((size_t)n);
             for (int64_t r = 0; r < n; ++r) {
                 int64_t x, y, z, d;
                 node_of(r, x, y, z, d);
                 const int64_t xs = x + sa * y + sb * z, ys = y + sc * z, zs = z;
-                const uint64_t tile = (uint64_t)(((zs / edge) * NYs + ys / edge) * NXs + xs / edge);
+                // tiles are numbered hyperplane by hyperplane (X' + Y' + Z' = const), not slab by slab: the tickets hand them
+                // out in this order, and the tiles a persistent grid holds at a time must be the ones that can run together
+                // (slab-major numbering left ~30 of 512 resident tiles runnable: 5 ms per sweep instead of 0.6)
+                const uint64_t lex = (uint64_t)(((zs / edge) * NYs + ys / edge) * NXs + xs / edge);
+                const uint64_t tile = (uint64_t)(zs / edge + ys / edge + xs / edge) * n_lex + lex;
                 const uint64_t intra = (uint64_t)((((zs % edge) * edge + ys % edge) * edge + xs % edge) * dof + d);
                 keyed[(size_t)r] = {tile * (uint64_t)(edge * edge * edge * dof) + intra, (int32_t)r};
             }
