@@ -64,13 +64,13 @@ constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
 constexpr int kMaxB = 32768;      // rows per tile at most
 constexpr int kOwn = 1024;        // LDS ring of the tile's own results (8 KiB), by slot: an in-tile operand must have been produced
                                   // fewer than kOwn - 64 slots before its consumer, else it is fetched like an external one
-constexpr int kExt = 2048;        // LDS ring of external operands (16 KiB), by ordinal (first-need order)
-constexpr int kExtWindow = 512;   // an ordinal may be used again while it is among the last kExtWindow ones first needed
+constexpr int kExt = 1024;        // LDS ring of external operands (8 KiB), by ordinal (first-need order)
+constexpr int kExtWindow = 256;   // an ordinal may be used again while it is among the last kExtWindow ones first needed
 constexpr int kZeroSlot = kOwn + kExt; // operand of padding entries: 0.0, so fma(0, 0, acc) leaves acc as it is
 constexpr int kOpnd = kOwn + kExt + 2;
-constexpr int kRingQ = 512;       // quad ring (LDS: 8 + 16 KiB)
+constexpr int kRingQ = 256;       // quad ring (LDS: 4 + 8 KiB)
 constexpr int kRingSlot = 512;    // per-row operand ring (LDS: 2 + 8 KiB)
-constexpr int kQuadChunk = 256;   // quads per loader round (4 per lane)
+constexpr int kQuadChunk = 128;   // quads per loader round (2 per lane)
 constexpr int kSlotChunk = 256;   // rows per loader round (4 per lane)
 constexpr int kPollBlock = 128;   // external ordinals the poller has in flight (2 per lane); its watermark moves block by block
 constexpr unsigned kSpinLds = 1u << 24;  // polls of an LDS word before a wave gives up (seconds)
@@ -682,7 +682,15 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
         hipMemsetAsync(dbg_buf, 0, sizeof(long long) * 8 * (size_t)p->n_tiles, ctx->stream);
         a.dbg = dbg_buf;
     }
-    const int per_cu = bis_opts().trsv_tile_wgs > 0 ? bis_opts().trsv_tile_wgs : 2;
+    // 39 KiB of LDS per workgroup: 4 workgroups per CU (the occupancy query has the last word)
+    static int resident = 0;
+    if (resident == 0) {
+        int nb = 0;
+        const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trsv_tiled_kernel<false>, 256, 0);
+        resident = (oe == hipSuccess && nb > 0) ? std::min(nb, 4) : 1;
+        (void)hipGetLastError();
+    }
+    const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, resident) : resident;
     const int grid = (int)std::min<int64_t>(p->n_tiles, (int64_t)ctx->n_cus * per_cu);
     if (dbg_file) hipLaunchKernelGGL(trsv_tiled_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(trsv_tiled_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
