@@ -34,6 +34,7 @@
 struct bis_trsv_tiled {
     int64_t n = 0;
     int n_tiles = 0, max_rows = 0;
+    bool lean = false;         // LDS budget the plan was laid out for (TiledCfg)
     int64_t n_steps = 0, n_quads = 0, n_ext = 0;
     // device arrays.  "slot" = position of a row in (tile, local level, processing order) order.
     int32_t *slot_row = nullptr;    // [n]  slot -> row
@@ -61,18 +62,26 @@ namespace {
 
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload (same as bis_sptrsv.hip)
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
+// LDS budget of a workgroup, two instantiations: LEAN (19 KiB: 8 workgroups = 32 waves per CU; rows of up to 8 entries --
+// the more tiles are resident, the more of them have their start-up loads behind them when their operands arrive) and
+// WIDE (38 KiB: 4 per CU; longer rows need room for a step's entries).
+template <int OWN, int EXT, int WINDOW, int RINGQ, int RINGSLOT, int QCHUNK, int SCHUNK>
+struct TiledCfg {
+    static constexpr int kOwn = OWN;         // LDS ring of the tile's own results, by slot: an in-tile operand must have been
+                                             // produced fewer than kOwn - 128 slots before its consumer, else it is fetched like an external one
+    static constexpr int kExt = EXT;         // LDS ring of external operands, by ordinal (first-need order)
+    static constexpr int kExtWindow = WINDOW; // an ordinal may be used again while it is among the last kExtWindow ones first needed
+    static constexpr int kZeroSlot = OWN + EXT; // operand of padding entries: 0.0, so fma(0, 0, acc) leaves acc as it is
+    static constexpr int kOpnd = OWN + EXT + 2;
+    static constexpr int kRingQ = RINGQ;     // quad ring (48 B per quad)
+    static constexpr int kRingSlot = RINGSLOT; // per-row operand ring (20 B per row)
+    static constexpr int kQuadChunk = QCHUNK; // quads per loader round
+    static constexpr int kSlotChunk = SCHUNK; // rows per loader round
+};
+using CfgLean = TiledCfg<512, 512, 128, 128, 256, 64, 128>;
+using CfgWide = TiledCfg<1024, 1024, 256, 256, 512, 128, 256>;
 constexpr int kMaxB = 32768;      // rows per tile at most
-constexpr int kOwn = 1024;        // LDS ring of the tile's own results (8 KiB), by slot: an in-tile operand must have been produced
-                                  // fewer than kOwn - 64 slots before its consumer, else it is fetched like an external one
-constexpr int kExt = 1024;        // LDS ring of external operands (8 KiB), by ordinal (first-need order)
-constexpr int kExtWindow = 256;   // an ordinal may be used again while it is among the last kExtWindow ones first needed
-constexpr int kZeroSlot = kOwn + kExt; // operand of padding entries: 0.0, so fma(0, 0, acc) leaves acc as it is
-constexpr int kOpnd = kOwn + kExt + 2;
-constexpr int kRingQ = 256;       // quad ring (LDS: 4 + 8 KiB)
-constexpr int kRingSlot = 512;    // per-row operand ring (LDS: 2 + 8 KiB)
-constexpr int kQuadChunk = 128;   // quads per loader round (2 per lane)
-constexpr int kSlotChunk = 256;   // rows per loader round (4 per lane)
-constexpr int kPollBlock = 128;   // external ordinals the poller has in flight (2 per lane); its watermark moves block by block
+constexpr int kPollBlock = 128;   // external ordinals the poller has in flight (2 per lane); its watermark moves with the leading delivered ordinal
 constexpr unsigned kSpinLds = 1u << 24;  // polls of an LDS word before a wave gives up (seconds)
 constexpr unsigned kSpinMem = 1u << 22;  // polls of a memory word
 
@@ -135,8 +144,10 @@ __device__ __forceinline__ int wave_min_int(int v) {
     return v;
 }
 
-template <bool DBG>
+template <typename CFG, bool DBG>
 __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
+    constexpr int kOwn = CFG::kOwn, kExt = CFG::kExt, kExtWindow = CFG::kExtWindow, kZeroSlot = CFG::kZeroSlot, kOpnd = CFG::kOpnd;
+    constexpr int kRingQ = CFG::kRingQ, kRingSlot = CFG::kRingSlot, kQuadChunk = CFG::kQuadChunk, kSlotChunk = CFG::kSlotChunk;
     // operands of the tile's rows, indexed directly by the entry codes (one LDS read per operand, no branch on where it
     // comes from): [0, kOwn) ring of the tile's own results by slot, [kOwn, kOwn + kExt) ring of the external operands
     // by ordinal, then the zero slot.
@@ -395,6 +406,10 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     if (st != BIS_OK) return st;
     int max_len = 0;
     for (int64_t r = 0; r < n; ++r) max_len = std::max<int>(max_len, (int)(rp[r + 1] - rp[r]));
+    const bool lean = max_len <= 8; // which LDS budget the sweep will run with (TiledCfg)
+    const int kOwn = lean ? CfgLean::kOwn : CfgWide::kOwn, kExt = lean ? CfgLean::kExt : CfgWide::kExt;
+    const int kExtWindow = lean ? CfgLean::kExtWindow : CfgWide::kExtWindow, kRingQ = lean ? CfgLean::kRingQ : CfgWide::kRingQ;
+    const int kZeroSlot = kOwn + kExt;
     if ((max_len + 3) / 4 > kRingQ / 2) return BIS_OK; // a single row must fit half the quad ring
     // The processing order: ord[pos] = row, any linear extension of the dependency order (every operand of a row sits
     // at an earlier position).  Default: the reference's substitution order (ascending rows forward, descending
@@ -623,7 +638,7 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     tile_ext0[n_tiles] = (int64_t)ext_src.size();
     // upload
     bis_trsv_tiled *p = new bis_trsv_tiled;
-    p->n = n; p->n_tiles = (int)n_tiles; p->max_rows = tile_rows_max;
+    p->n = n; p->n_tiles = (int)n_tiles; p->max_rows = tile_rows_max; p->lean = lean;
     p->n_steps = (int64_t)step_desc.size();
     p->n_quads = (int64_t)quad_code.size();
     p->n_ext = (int64_t)ext_src.size();
@@ -682,18 +697,25 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
         hipMemsetAsync(dbg_buf, 0, sizeof(long long) * 8 * (size_t)p->n_tiles, ctx->stream);
         a.dbg = dbg_buf;
     }
-    // 39 KiB of LDS per workgroup: 4 workgroups per CU (the occupancy query has the last word)
-    static int resident = 0;
-    if (resident == 0) {
+    // LEAN: 19 KiB of LDS per workgroup, 8 workgroups per CU; WIDE: 38 KiB, 4 per CU (the occupancy query has the last word)
+    static int resident[2] = {0, 0};
+    int &res = resident[p->lean ? 0 : 1];
+    if (res == 0) {
         int nb = 0;
-        const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trsv_tiled_kernel<false>, 256, 0);
-        resident = (oe == hipSuccess && nb > 0) ? std::min(nb, 4) : 1;
+        const hipError_t oe = p->lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trsv_tiled_kernel<CfgLean, false>, 256, 0)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trsv_tiled_kernel<CfgWide, false>, 256, 0);
+        res = (oe == hipSuccess && nb > 0) ? std::min(nb, 8) : 1;
         (void)hipGetLastError();
     }
-    const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, resident) : resident;
+    const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, res) : res;
     const int grid = (int)std::min<int64_t>(p->n_tiles, (int64_t)ctx->n_cus * per_cu);
-    if (dbg_file) hipLaunchKernelGGL(trsv_tiled_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(trsv_tiled_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    if (p->lean) {
+        if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else {
+        if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    }
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (dbg_file) {
         std::vector<long long> h((size_t)p->n_tiles * 8);
