@@ -417,7 +417,10 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     std::vector<int32_t> ord((size_t)n), pos_v((size_t)n);
     std::vector<int64_t> tile_pos0;
     bool grid_tiles = false;
-    const int edge = bis_opts().trsv_tile_edge >= 0 ? bis_opts().trsv_tile_edge : 16;
+    // tile extents in nodes: trsv_tile_edge = e (cubic) or ex | ey << 8 | ez << 16; default 16 x 8 x 8 ... see the measurements below
+    const int edge_opt = bis_opts().trsv_tile_edge >= 0 ? bis_opts().trsv_tile_edge : (8 | 8 << 8 | 8 << 16);
+    const int ex = edge_opt < 256 ? edge_opt : (edge_opt & 255), ey = edge_opt < 256 ? edge_opt : ((edge_opt >> 8) & 255), ez = edge_opt < 256 ? edge_opt : ((edge_opt >> 16) & 255);
+    const int edge = std::min(ex, std::min(ey, ez));
     if (T->grid[0] > 0 && edge > 0 && T->grid[0] * T->grid[1] * T->grid[2] * T->grid[3] == n) {
         // Skewed tile-major order.  Node coordinates are mirrored for the backward sweep, so that in both directions an
         // operand has a SMALLER node (or the same node and a smaller unknown).  With x' = x + a y + b z, y' = y + c z,
@@ -465,8 +468,8 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                     }
         }
         if (sa >= 0) {
-            const int64_t NXs = (nx + sa * (ny - 1) + sb * (nz - 1) + edge - 1) / edge, NYs = (ny + sc * (nz - 1) + edge - 1) / edge;
-            const uint64_t n_lex = (uint64_t)(((nz + edge - 1) / edge) * NYs * NXs);
+            const int64_t NXs = (nx + sa * (ny - 1) + sb * (nz - 1) + ex - 1) / ex, NYs = (ny + sc * (nz - 1) + ey - 1) / ey;
+            const uint64_t n_lex = (uint64_t)(((nz + ez - 1) / ez) * NYs * NXs);
             std::vector<std::pair<uint64_t, int32_t>> keyed((size_t)n);
             for (int64_t r = 0; r < n; ++r) {
                 int64_t x, y, z, d;
@@ -475,13 +478,13 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                 // tiles are numbered hyperplane by hyperplane (X' + Y' + Z' = const), not slab by slab: the tickets hand them
                 // out in this order, and the tiles a persistent grid holds at a time must be the ones that can run together
                 // (slab-major numbering left ~30 of 512 resident tiles runnable: 5 ms per sweep instead of 0.6)
-                const uint64_t lex = (uint64_t)(((zs / edge) * NYs + ys / edge) * NXs + xs / edge);
-                const uint64_t tile = (uint64_t)(zs / edge + ys / edge + xs / edge) * n_lex + lex;
-                const uint64_t intra = (uint64_t)((((zs % edge) * edge + ys % edge) * edge + xs % edge) * dof + d);
-                keyed[(size_t)r] = {tile * (uint64_t)(edge * edge * edge * dof) + intra, (int32_t)r};
+                const uint64_t lex = (uint64_t)(((zs / ez) * NYs + ys / ey) * NXs + xs / ex);
+                const uint64_t tile = (uint64_t)(zs / ez + ys / ey + xs / ex) * n_lex + lex;
+                const uint64_t intra = (uint64_t)((((zs % ez) * ey + ys % ey) * ex + xs % ex) * dof + d);
+                keyed[(size_t)r] = {tile * (uint64_t)((int64_t)ex * ey * ez * dof) + intra, (int32_t)r};
             }
             std::sort(keyed.begin(), keyed.end());
-            const uint64_t tile_vol = (uint64_t)(edge * edge * edge * dof);
+            const uint64_t tile_vol = (uint64_t)((int64_t)ex * ey * ez * dof);
             bool fits = tile_vol <= (uint64_t)kMaxB;
             for (int64_t p = 0; p < n; ++p) { ord[(size_t)p] = keyed[(size_t)p].second; pos_v[(size_t)keyed[(size_t)p].second] = (int32_t)p; }
             // a linear extension?
