@@ -80,7 +80,7 @@ struct bis_options {
     int trsv_tiled = -1;    // natural-order sweeps: 1 = tiled sweep (bis_trsv_tiled.hip; opt-in: its plan is built on the host), else level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
-    int trsv_tile_edge = -1; // grid-hinted matrices: edge of the cubic tiles in nodes (default 16; 0 = interval tiles of the natural order)
+    int trsv_tile_edge = -1; // grid-hinted matrices: tile extents in nodes, e (cubic) or ex | ey << 8 | ez << 16 (default by row length; 0 = interval tiles of the natural order)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
     int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes
 };

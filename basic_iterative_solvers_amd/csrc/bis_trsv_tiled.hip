@@ -417,8 +417,15 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
     std::vector<int32_t> ord((size_t)n), pos_v((size_t)n);
     std::vector<int64_t> tile_pos0;
     bool grid_tiles = false;
-    // tile extents in nodes: trsv_tile_edge = e (cubic) or ex | ey << 8 | ez << 16; default 16 x 8 x 8 ... see the measurements below
-    const int edge_opt = bis_opts().trsv_tile_edge >= 0 ? bis_opts().trsv_tile_edge : (8 | 8 << 8 | 8 << 16);
+    // tile extents in nodes: trsv_tile_edge = e (cubic) or ex | ey << 8 | ez << 16.  Defaults from tools/trsv_ab.py, forward /
+    // backward sweep in ms (level-scheduled kernels: 2.53 / 2.51, 2.21 / 2.37, 3.42 / 4.95):
+    //   7-point 256^3 (3 operands per row): 8x8x8 0.84 / 0.84; 6^3 1.14; 12x8x8 0.97; 16x8x8 1.05; 32x8x4 1.07; 16^3 2.5
+    //   27-point 128^3 (13):                 8x4x4 0.94 / 0.98; 16x4x2 1.03; 16x4x4 1.05; 32x4x4 1.14; 6^3 1.41; 8^3 2.24
+    //   FEM-like 80x80x81x3 (~35):           2x2x2 2.83 / 2.82; 4x2x2 3.27; 3^3 3.75; 8x2x2 4.9
+    // small tiles win: a hop costs the tile's extent in levels plus a memory round trip, and ~1800 resident tiles hide the
+    // start-up loads of the ones whose turn comes next
+    const int edge_default = max_len <= 8 ? (8 | 8 << 8 | 8 << 16) : max_len <= 16 ? (8 | 4 << 8 | 4 << 16) : (2 | 2 << 8 | 2 << 16);
+    const int edge_opt = bis_opts().trsv_tile_edge >= 0 ? bis_opts().trsv_tile_edge : edge_default;
     const int ex = edge_opt < 256 ? edge_opt : (edge_opt & 255), ey = edge_opt < 256 ? edge_opt : ((edge_opt >> 8) & 255), ez = edge_opt < 256 ? edge_opt : ((edge_opt >> 16) & 255);
     const int edge = std::min(ex, std::min(ey, ez));
     if (T->grid[0] > 0 && edge > 0 && T->grid[0] * T->grid[1] * T->grid[2] * T->grid[3] == n) {
@@ -710,7 +717,8 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
         res = (oe == hipSuccess && nb > 0) ? std::min(nb, 8) : 1;
         (void)hipGetLastError();
     }
-    const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, res) : res;
+    // measured on the 7-point 256^3 grid (8^3 tiles): 3 / 4 / 5 / 7 workgroups per CU 0.88 / 0.84 / 0.85 / 0.95 ms
+    const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, res) : std::min(res, 4);
     const int grid = (int)std::min<int64_t>(p->n_tiles, (int64_t)ctx->n_cus * per_cu);
     if (p->lean) {
         if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, true>), dim3(grid), dim3(256), 0, ctx->stream, a);

@@ -14,11 +14,14 @@ run anderson:256,shift=9 -gm -p gs -perm mc
 run anderson:256,shift=9 -gm -p gs -perm rcm
 run fem:80,80,81 -bi -p ilu0
 run fem:80,80,81 -bi -p ilu0 -hostscalars
+run fem:80,80,81 -bi -p ilu0 -trsv tiled
 run fem:80,80,81 -bi -p ilu0 -perm mc
 run fem:80,80,81 -cg -p j
 run hpcg:256 -cg -p sgs -perm mc
 run hpcg:128 -cg -p sgs
 run hpcg:128 -cg -p sgs -trsv tiled
+run anderson:256,shift=9 -gs
+run anderson:256,shift=9 -gs -trsv tiled
 export BIS_TIMERS_SYNC=1
 run anderson:256,shift=9 -gm -p gs
 run fem:80,80,81 -bi -p ilu0
