@@ -349,6 +349,9 @@ class Mat:
     def rp_width(self):
         return int(self.ctx.lib.bis_mat_rp_width(self.h))
 
+    def set_grid_hint(self, nx, ny, nz, dof=1):
+        self.ctx.check(self.ctx.lib.bis_mat_set_grid_hint(self.h, _i64(nx), _i64(ny), _i64(nz), C.c_int(dof)))
+
     def download(self):
         rp = np.zeros(self.n_rows + 1, dtype=np.int64)
         col = np.zeros(self.nnz, dtype=np.int32)

@@ -524,7 +524,7 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
         BIS_HIP_CHECK(ctx, hipGetLastError());
         return BIS_OK;
     }
-    if (bis_opts().trsv_tiled > 0 && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_one_xcd <= 0) { // opt-in: DESIGN.md section 4
+    if (bis_opts().trsv_tiled != 0 && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_one_xcd <= 0) { // DESIGN.md section 4; modes: bis_trsv_tiled_build
         if (!p->tiled_tried) {
             p->tiled_tried = true;
             st = bis_trsv_tiled_build(ctx, T, backward, &p->tiled);

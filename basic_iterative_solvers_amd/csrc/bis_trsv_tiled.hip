@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <numeric>
+#include <rocprim/rocprim.hpp>
 
 struct bis_trsv_tiled {
     int64_t n = 0;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
 // ---- plan (host analysis) ---------------------------------------------------------------------------
 // Input: the strictly triangular pattern on the host.  Output: the processing order, its tiles, and per tile the
 // steps, the repacked entries and the list of external operands.
-bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_tiled **out) {
+static bis_status trsv_tiled_build_host(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_tiled **out) {
     *out = nullptr;
     const int64_t n = T->n_rows;
     if (n == 0 || T->nnz == 0 || T->nnz > (int64_t)600000000 || T->view) return BIS_OK; // not applicable: caller keeps the level-scheduled sweep
@@ -691,6 +692,433 @@ bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, b
                 (long long)n_demoted, grid_tiles ? "; grid tiles" : "; interval tiles");
     *out = p;
     return BIS_OK;
+}
+
+// ---- plan (device analysis, grid-hinted matrices) ----------------------------------------------------
+// The same plan as trsv_tiled_build_host, array for array, built where the matrix lives: the skew search is a bit
+// mask reduced over all entries, the order a radix sort of the tile keys, and the per-tile work (local levels, steps,
+// quads, external ordinals) the host's sequential loop run by ONE LANE PER TILE -- tens of thousands of tiles run
+// side by side, which is all the parallelism this needs (measured: DESIGN.md section 4).  Sizes are data dependent, so
+// the per-tile pass runs twice: count, scan, fill.
+namespace {
+
+struct PlanGeom {
+    long long nx, ny, nz, dof, NXs, NYs;
+    unsigned long long n_lex, tile_vol;
+    int backward, sa, sb, sc, ex, ey, ez;
+};
+
+__device__ __forceinline__ void plan_node(const PlanGeom &g, long long row, long long &x, long long &y, long long &z, long long &d) {
+    d = row % g.dof;
+    const long long a0 = row / g.dof;
+    x = a0 % g.nx; y = (a0 / g.nx) % g.ny; z = a0 / (g.nx * g.ny);
+    if (g.backward) { x = g.nx - 1 - x; y = g.ny - 1 - y; z = g.nz - 1 - z; d = g.dof - 1 - d; }
+}
+
+// bit (a + 4 b + 16 c) of *mask survives iff every operand offset has x' <= 0, y' <= 0, z' <= 0 under the skew (a, b, c)
+template <class RP>
+__global__ __launch_bounds__(256) void plan_skew_kernel(PlanGeom g, int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+                                                        unsigned long long *mask) {
+    unsigned long long m = ~0ull;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
+        long long x, y, z, d;
+        plan_node(g, r, x, y, z, d);
+        for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+            long long cx, cy, cz, cd;
+            plan_node(g, col[k], cx, cy, cz, cd);
+            const long long dx = cx - x, dy = cy - y, dz = cz - z;
+            if (dz > 0) { m = 0; continue; }
+            for (int c = 0; c < 4; ++c) {
+                if (dy + c * dz > 0) { m &= ~(0xFFFFull << (16 * c)); continue; }
+                for (int b = 0; b < 4; ++b)
+                    for (int a = 0; a < 4; ++a)
+                        if (dx + a * dy + b * dz > 0) m &= ~(1ull << (a + 4 * b + 16 * c));
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) m &= __shfl_xor(m, o);
+    if ((threadIdx.x & 63) == 0 && m != ~0ull) atomicAnd(mask, m);
+}
+
+__global__ __launch_bounds__(256) void plan_key_kernel(PlanGeom g, int64_t n, unsigned long long *__restrict__ key, int32_t *__restrict__ row) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
+        long long x, y, z, d;
+        plan_node(g, r, x, y, z, d);
+        const long long xs = x + g.sa * y + g.sb * z, ys = y + g.sc * z, zs = z;
+        const unsigned long long lex = (unsigned long long)(((zs / g.ez) * g.NYs + ys / g.ey) * g.NXs + xs / g.ex);
+        const unsigned long long tile = (unsigned long long)(zs / g.ez + ys / g.ey + xs / g.ex) * g.n_lex + lex;
+        const unsigned long long intra = (unsigned long long)((((zs % g.ez) * g.ey + ys % g.ey) * g.ex + xs % g.ex) * g.dof + d);
+        key[r] = tile * g.tile_vol + intra;
+        row[r] = (int32_t)r;
+    }
+}
+
+template <class RP>
+__global__ __launch_bounds__(256) void plan_pos_kernel(int64_t n, unsigned long long tile_vol, const unsigned long long *__restrict__ key,
+                                                       const int32_t *__restrict__ ord, const RP *__restrict__ rp, int32_t *__restrict__ pos,
+                                                       int32_t *__restrict__ flag, int64_t *__restrict__ len) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += stride) {
+        const int32_t r = ord[p];
+        pos[r] = (int32_t)p;
+        flag[p] = (p == 0 || key[p] / tile_vol != key[p - 1] / tile_vol) ? 1 : 0;
+        len[p] = (int64_t)(rp[r + 1] - rp[r]);
+    }
+}
+
+__global__ __launch_bounds__(256) void plan_tiles_kernel(int64_t n, int64_t n_tiles, const int32_t *__restrict__ flag, const int32_t *__restrict__ tix,
+                                                         int64_t *__restrict__ tile_pos0) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += stride) {
+        if (flag[p]) tile_pos0[tix[p] - 1] = p;
+        if (p == 0) tile_pos0[n_tiles] = n;
+    }
+}
+
+// the order must be a linear extension of the dependency order
+template <class RP>
+__global__ __launch_bounds__(256) void plan_verify_kernel(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+                                                          const int32_t *__restrict__ pos, int *bad) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    bool b = false;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
+        const int32_t pr = pos[r];
+        for (int64_t k = rp[r]; k < rp[r + 1]; ++k) b |= pos[col[k]] >= pr;
+    }
+    if (b) *bad = 1;
+}
+
+struct PlanArgs {
+    int64_t n, nnz, n_tiles;
+    const void *rp;
+    const int32_t *col;
+    const double *val;
+    const int64_t *tile_pos0;
+    const int32_t *ord, *pos, *tix;
+    const int64_t *entpos;
+    int32_t *lvl, *cnt, *fill, *order, *lidx, *tile_maxlvl;
+    int32_t *slot_row;
+    int32_t *hash_key, *hash_ord;
+    int64_t *n_steps, *n_quads, *n_ext; // per tile: counts (pass 1), then their exclusive scans (pass 2)
+    int4 *step_desc, *quad_code;
+    double *quad_val;
+    int32_t *ext_src;
+    unsigned long long *n_demoted;
+    int kOwn, kExt, kExtWindow, kRingQ, kZeroSlot;
+};
+
+// local levels and the (level, processing order) sort of each tile: slot_row, lidx
+template <class RP>
+__global__ __launch_bounds__(64) void plan_levels_kernel(PlanArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= a.n_tiles) return;
+    const RP *rp = (const RP *)a.rp;
+    const int64_t p0 = a.tile_pos0[t];
+    const int m = (int)(a.tile_pos0[t + 1] - p0);
+    int32_t *lvl = a.lvl + p0, *order = a.order + p0, *cnt = a.cnt + p0 + 2 * t, *fill = a.fill + p0 + 2 * t;
+    int max_lvl = 0;
+    for (int i = 0; i < m; ++i) { // in-tile dependencies sit at earlier positions of the tile
+        const int64_t r = a.ord[p0 + i];
+        int l = 0;
+        for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+            const int64_t q = a.pos[a.col[k]];
+            if (q >= p0) l = max(l, lvl[(int)(q - p0)] + 1);
+        }
+        lvl[i] = l;
+        max_lvl = max(max_lvl, l);
+    }
+    for (int l = 0; l < max_lvl + 2; ++l) cnt[l] = 0; // stable counting sort by level
+    for (int i = 0; i < m; ++i) cnt[lvl[i] + 1]++;
+    for (int l = 0; l <= max_lvl; ++l) cnt[l + 1] += cnt[l];
+    for (int l = 0; l <= max_lvl; ++l) fill[l] = cnt[l];
+    for (int i = 0; i < m; ++i) order[fill[lvl[i]]++] = i;
+    for (int s = 0; s < m; ++s) {
+        const int32_t r = a.ord[p0 + order[s]];
+        a.slot_row[p0 + s] = r;
+        a.lidx[r] = s;
+    }
+    a.tile_maxlvl[t] = max_lvl;
+}
+
+// steps, quads and external ordinals of each tile; FILL = false counts, FILL = true writes at the scanned offsets
+template <class RP, bool FILL>
+__global__ __launch_bounds__(64) void plan_steps_kernel(PlanArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= a.n_tiles) return;
+    const RP *rp = (const RP *)a.rp;
+    const int64_t p0 = a.tile_pos0[t];
+    const int m = (int)(a.tile_pos0[t + 1] - p0);
+    const int32_t *cnt = a.cnt + p0 + 2 * t;
+    const int max_lvl = a.tile_maxlvl[t];
+    const int64_t e0 = a.entpos[p0];
+    const int64_t E = (p0 + m < a.n ? a.entpos[p0 + m] : a.nnz) - e0;
+    unsigned cap = 4; // the tile's own hash table (slot of an external operand -> its ordinal): 4 E words reserved, at most half full
+    while ((int64_t)cap < 2 * E) cap <<= 1;
+    int32_t *hk = a.hash_key + 4 * e0, *ho = a.hash_ord + 4 * e0;
+    const int64_t step0 = FILL ? a.n_steps[t] : 0, quad0 = FILL ? a.n_quads[t] : 0, ext0 = FILL ? a.n_ext[t] : 0;
+    int64_t step_i = 0, quad_i = 0;
+    int n_ext_tile = 0;
+    unsigned long long demoted = 0;
+    for (int l = 0; l <= max_lvl; ++l) {
+        int s = cnt[l];
+        const int s_end = cnt[l + 1];
+        while (s < s_end) { // steps: runs of one level, at most 64 rows, at most kRingQ/2 quads
+            int w = 0, nq = 0;
+            while (s + w < s_end && w < 64) {
+                const int64_t r = a.slot_row[p0 + s + w];
+                const int nq2 = max(nq, (int)((rp[r + 1] - rp[r] + 3) / 4));
+                if (w > 0 && (w + 1) * nq2 > a.kRingQ / 2) break;
+                nq = nq2;
+                ++w;
+            }
+            const int quad_b = (int)quad_i;
+            const int ext_base = n_ext_tile; // ordinals first needed before this step
+            for (int g = 0; g < nq; ++g)
+                for (int i = 0; i < w; ++i) {
+                    const int64_t r = a.slot_row[p0 + s + i];
+                    const int64_t k0 = rp[r], k1 = rp[r + 1];
+                    int code[4];
+                    double v[4];
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t kk = k0 + 4 * g + q;
+                        if (kk >= k1) { code[q] = a.kZeroSlot; v[q] = 0.0; continue; }
+                        const int32_t c = a.col[kk];
+                        if (FILL) v[q] = a.val[kk];
+                        const int64_t qp = a.pos[c];
+                        const int ps = a.lidx[c]; // the operand's slot within ITS tile
+                        if (qp >= p0 && (s + i) - ps <= a.kOwn - 128) {
+                            code[q] = ps & (a.kOwn - 1); // still in the ring of the tile's own results
+                        } else { // another tile's result, or one of this tile's that has left the ring: through the poller
+                            if (qp >= p0) ++demoted;
+                            const int32_t gs = (int32_t)(a.tile_pos0[a.tix[qp] - 1] + ps);
+                            unsigned h = ((unsigned)gs * 2654435761u) & (cap - 1);
+                            while (hk[h] != -1 && hk[h] != gs) h = (h + 1) & (cap - 1);
+                            if (hk[h] != gs || ho[h] < ext_base - a.kExtWindow) { // first need, or last listed too long ago: next ordinal
+                                hk[h] = gs;
+                                ho[h] = n_ext_tile;
+                                if (FILL) a.ext_src[ext0 + n_ext_tile] = gs;
+                                ++n_ext_tile;
+                            }
+                            code[q] = a.kOwn + (ho[h] & (a.kExt - 1));
+                        }
+                    }
+                    if (FILL) {
+                        a.quad_code[quad0 + quad_i] = make_int4(code[0], code[1], code[2], code[3]);
+                        double2 *qv = (double2 *)(a.quad_val + 4 * (quad0 + quad_i));
+                        qv[0] = make_double2(v[0], v[1]);
+                        qv[1] = make_double2(v[2], v[3]);
+                    }
+                    ++quad_i;
+                }
+            if (FILL) a.step_desc[step0 + step_i] = make_int4(s, w | (nq << 8), quad_b, n_ext_tile);
+            ++step_i;
+            s += w;
+        }
+    }
+    if (!FILL) {
+        a.n_steps[t] = step_i; a.n_quads[t] = quad_i; a.n_ext[t] = n_ext_tile;
+        if (demoted) atomicAdd(a.n_demoted, demoted);
+    }
+}
+
+struct DevBufs { // scratch of the device plan, freed on every way out
+    std::vector<void *> v;
+    hipError_t e = hipSuccess;
+    template <class T> T *get(size_t count) {
+        void *p = nullptr;
+        if (e == hipSuccess) e = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16));
+        if (e == hipSuccess) v.push_back(p); else p = nullptr;
+        return (T *)p;
+    }
+    ~DevBufs() { for (void *p : v) hipFree(p); }
+};
+
+} // namespace
+
+// *out stays null (BIS_OK) when the grid hint does not give a valid tile order
+static bis_status trsv_tiled_build_device(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_tiled **out) {
+    *out = nullptr;
+    const int64_t n = T->n_rows;
+    if (n == 0 || T->nnz == 0 || T->nnz > (int64_t)600000000 || T->view || n >= INT32_MAX) return BIS_OK;
+    if (!(T->grid[0] > 0 && T->grid[0] * T->grid[1] * T->grid[2] * T->grid[3] == n)) return BIS_OK;
+    const int max_len = T->max_row_nnz;
+    const bool lean = max_len <= 8;
+    PlanArgs a{};
+    a.kOwn = lean ? CfgLean::kOwn : CfgWide::kOwn; a.kExt = lean ? CfgLean::kExt : CfgWide::kExt;
+    a.kExtWindow = lean ? CfgLean::kExtWindow : CfgWide::kExtWindow; a.kRingQ = lean ? CfgLean::kRingQ : CfgWide::kRingQ;
+    a.kZeroSlot = a.kOwn + a.kExt;
+    if ((max_len + 3) / 4 > a.kRingQ / 2) return BIS_OK;
+    const int edge_default = max_len <= 8 ? (8 | 8 << 8 | 8 << 16) : max_len <= 16 ? (8 | 4 << 8 | 4 << 16) : (2 | 2 << 8 | 2 << 16); // measured: trsv_tiled_build_host
+    const int edge_opt = bis_opts().trsv_tile_edge >= 0 ? bis_opts().trsv_tile_edge : edge_default;
+    PlanGeom g{};
+    g.nx = T->grid[0]; g.ny = T->grid[1]; g.nz = T->grid[2]; g.dof = T->grid[3]; g.backward = backward ? 1 : 0;
+    g.ex = edge_opt < 256 ? edge_opt : (edge_opt & 255); g.ey = edge_opt < 256 ? edge_opt : ((edge_opt >> 8) & 255);
+    g.ez = edge_opt < 256 ? edge_opt : ((edge_opt >> 16) & 255);
+    if (std::min(g.ex, std::min(g.ey, g.ez)) <= 0) return BIS_OK;
+    g.tile_vol = (unsigned long long)((long long)g.ex * g.ey * g.ez * g.dof);
+    if (g.tile_vol > (unsigned long long)kMaxB) return BIS_OK;
+    hipStream_t s = ctx->stream;
+    DevBufs B;
+    const int grid_n = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->n_cus * 16);
+    auto fail = [&](hipError_t e) { ctx->err = std::string("tiled sptrsv plan: ") + hipGetErrorString(e); return BIS_ERR_HIP; };
+#define PLAN_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_); } while (0)
+#define PLAN_RP(kernel, grid, block, ...) do { \
+        if (T->rp64) hipLaunchKernelGGL((kernel<int64_t>), dim3(grid), dim3(block), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kernel<int32_t>), dim3(grid), dim3(block), 0, s, __VA_ARGS__); \
+        PLAN_CHECK(hipGetLastError()); } while (0)
+    // the smallest skew under which every operand offset points backwards
+    unsigned long long *d_mask = B.get<unsigned long long>(1);
+    int *d_bad = B.get<int>(1);
+    PLAN_CHECK(B.e);
+    PLAN_CHECK(hipMemsetAsync(d_mask, 0xFF, 8, s));
+    PLAN_CHECK(hipMemsetAsync(d_bad, 0, 4, s));
+    if (T->rp64) hipLaunchKernelGGL(plan_skew_kernel<int64_t>, dim3(grid_n), dim3(256), 0, s, g, n, (const int64_t *)T->row_ptr, T->col, d_mask);
+    else hipLaunchKernelGGL(plan_skew_kernel<int32_t>, dim3(grid_n), dim3(256), 0, s, g, n, (const int32_t *)T->row_ptr, T->col, d_mask);
+    PLAN_CHECK(hipGetLastError());
+    unsigned long long mask = 0;
+    PLAN_CHECK(hipMemcpyAsync(&mask, d_mask, 8, hipMemcpyDeviceToHost, s));
+    PLAN_CHECK(hipStreamSynchronize(s));
+    int sa = -1, sb = -1, sc = -1;
+    for (int tot = 0; tot <= 9 && sa < 0; ++tot)
+        for (int a2 = 0; a2 <= 3 && sa < 0; ++a2)
+            for (int b2 = 0; b2 <= 3 && sa < 0; ++b2) {
+                const int c2 = tot - a2 - b2;
+                if (c2 < 0 || c2 > 3) continue;
+                if (mask >> (a2 + 4 * b2 + 16 * c2) & 1) { sa = a2; sb = b2; sc = c2; }
+            }
+    if (sa < 0) return BIS_OK;
+    g.sa = sa; g.sb = sb; g.sc = sc;
+    g.NXs = (g.nx + sa * (g.ny - 1) + sb * (g.nz - 1) + g.ex - 1) / g.ex;
+    g.NYs = (g.ny + sc * (g.nz - 1) + g.ey - 1) / g.ey;
+    const long long NZs = (g.nz + g.ez - 1) / g.ez;
+    g.n_lex = (unsigned long long)(NZs * g.NYs * g.NXs);
+    const unsigned long long key_max = (unsigned long long)(NZs + g.NYs + g.NXs) * g.n_lex * g.tile_vol;
+    int key_bits = 1;
+    while (key_bits < 64 && (key_max >> key_bits) != 0) ++key_bits;
+    // order: sort the rows by (hyperplane of tiles, tile, place in the tile)
+    unsigned long long *key_in = B.get<unsigned long long>((size_t)n), *key = B.get<unsigned long long>((size_t)n);
+    int32_t *row_in = B.get<int32_t>((size_t)n), *ord = B.get<int32_t>((size_t)n), *pos = B.get<int32_t>((size_t)n);
+    int32_t *flag = B.get<int32_t>((size_t)n), *tix = B.get<int32_t>((size_t)n);
+    int64_t *len = B.get<int64_t>((size_t)n), *entpos = B.get<int64_t>((size_t)n);
+    PLAN_CHECK(B.e);
+    hipLaunchKernelGGL(plan_key_kernel, dim3(grid_n), dim3(256), 0, s, g, n, key_in, row_in);
+    PLAN_CHECK(hipGetLastError());
+    {
+        size_t b_sort = 0, b_scan32 = 0, b_scan64 = 0;
+        PLAN_CHECK(rocprim::radix_sort_pairs(nullptr, b_sort, key_in, key, row_in, ord, (size_t)n, 0, key_bits, s));
+        PLAN_CHECK(rocprim::inclusive_scan(nullptr, b_scan32, flag, tix, (size_t)n, rocprim::plus<int32_t>(), s));
+        PLAN_CHECK(rocprim::exclusive_scan(nullptr, b_scan64, len, entpos, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s));
+        const size_t b_tmp = std::max(b_sort, std::max(b_scan32, b_scan64));
+        char *tmp = B.get<char>(b_tmp);
+        PLAN_CHECK(B.e);
+        size_t bb = b_tmp;
+        PLAN_CHECK(rocprim::radix_sort_pairs(tmp, bb, key_in, key, row_in, ord, (size_t)n, 0, key_bits, s));
+        if (T->rp64) hipLaunchKernelGGL(plan_pos_kernel<int64_t>, dim3(grid_n), dim3(256), 0, s, n, g.tile_vol, key, ord, (const int64_t *)T->row_ptr, pos, flag, len);
+        else hipLaunchKernelGGL(plan_pos_kernel<int32_t>, dim3(grid_n), dim3(256), 0, s, n, g.tile_vol, key, ord, (const int32_t *)T->row_ptr, pos, flag, len);
+        PLAN_CHECK(hipGetLastError());
+        bb = b_tmp;
+        PLAN_CHECK(rocprim::inclusive_scan(tmp, bb, flag, tix, (size_t)n, rocprim::plus<int32_t>(), s));
+        bb = b_tmp;
+        PLAN_CHECK(rocprim::exclusive_scan(tmp, bb, len, entpos, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s));
+    }
+    if (T->rp64) hipLaunchKernelGGL(plan_verify_kernel<int64_t>, dim3(grid_n), dim3(256), 0, s, n, (const int64_t *)T->row_ptr, T->col, pos, d_bad);
+    else hipLaunchKernelGGL(plan_verify_kernel<int32_t>, dim3(grid_n), dim3(256), 0, s, n, (const int32_t *)T->row_ptr, T->col, pos, d_bad);
+    PLAN_CHECK(hipGetLastError());
+    int32_t n_tiles32 = 0;
+    int bad = 0;
+    PLAN_CHECK(hipMemcpyAsync(&n_tiles32, tix + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    PLAN_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+    PLAN_CHECK(hipStreamSynchronize(s));
+    if (bad) return BIS_OK; // a pattern the hint does not describe
+    const int64_t n_tiles = n_tiles32;
+    bis_trsv_tiled *p = new bis_trsv_tiled;
+    struct Guard { bis_trsv_tiled *p; ~Guard() { bis_trsv_tiled_destroy(p); } } guard{p};
+    p->n = n; p->n_tiles = (int)n_tiles; p->lean = lean;
+    PLAN_CHECK(hipMalloc(&p->tile_slot0, 8 * (size_t)(n_tiles + 1)));
+    PLAN_CHECK(hipMalloc(&p->tile_step0, 8 * (size_t)(n_tiles + 1)));
+    PLAN_CHECK(hipMalloc(&p->tile_quad0, 8 * (size_t)(n_tiles + 1)));
+    PLAN_CHECK(hipMalloc(&p->tile_ext0, 8 * (size_t)(n_tiles + 1)));
+    PLAN_CHECK(hipMalloc(&p->slot_row, 4 * (size_t)n));
+    PLAN_CHECK(hipMalloc(&p->xs, sizeof(double) * (size_t)(n + 1)));
+    PLAN_CHECK(hipMalloc(&p->ticket, sizeof(unsigned) * 4));
+    hipLaunchKernelGGL(plan_tiles_kernel, dim3(grid_n), dim3(256), 0, s, n, n_tiles, flag, tix, p->tile_slot0);
+    PLAN_CHECK(hipGetLastError());
+    // per tile: levels and slots, then count / scan / fill of steps, quads and external ordinals
+    a.n = n; a.nnz = T->nnz; a.n_tiles = n_tiles; a.rp = T->row_ptr; a.col = T->col; a.val = T->val;
+    a.tile_pos0 = p->tile_slot0; a.ord = ord; a.pos = pos; a.tix = tix; a.entpos = entpos;
+    a.lvl = B.get<int32_t>((size_t)n); a.order = B.get<int32_t>((size_t)n); a.lidx = B.get<int32_t>((size_t)n);
+    a.cnt = B.get<int32_t>((size_t)(n + 2 * n_tiles)); a.fill = B.get<int32_t>((size_t)(n + 2 * n_tiles));
+    a.tile_maxlvl = B.get<int32_t>((size_t)n_tiles);
+    a.hash_key = B.get<int32_t>(4 * (size_t)T->nnz + 4); a.hash_ord = B.get<int32_t>(4 * (size_t)T->nnz + 4);
+    a.n_demoted = B.get<unsigned long long>(1);
+    a.slot_row = p->slot_row;
+    a.n_steps = p->tile_step0; a.n_quads = p->tile_quad0; a.n_ext = p->tile_ext0;
+    PLAN_CHECK(B.e);
+    PLAN_CHECK(hipMemsetAsync(a.n_demoted, 0, 8, s));
+    PLAN_CHECK(hipMemsetAsync(a.hash_key, 0xFF, 4 * (4 * (size_t)T->nnz + 4), s));
+    PLAN_CHECK(hipMemsetAsync(p->tile_step0, 0, 8 * (size_t)(n_tiles + 1), s));
+    PLAN_CHECK(hipMemsetAsync(p->tile_quad0, 0, 8 * (size_t)(n_tiles + 1), s));
+    PLAN_CHECK(hipMemsetAsync(p->tile_ext0, 0, 8 * (size_t)(n_tiles + 1), s));
+    const int grid_t = (int)((n_tiles + 63) / 64);
+    PLAN_RP(plan_levels_kernel, grid_t, 64, a);
+    if (T->rp64) hipLaunchKernelGGL((plan_steps_kernel<int64_t, false>), dim3(grid_t), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((plan_steps_kernel<int32_t, false>), dim3(grid_t), dim3(64), 0, s, a);
+    PLAN_CHECK(hipGetLastError());
+    {
+        size_t b_scan = 0;
+        PLAN_CHECK(rocprim::exclusive_scan(nullptr, b_scan, p->tile_step0, p->tile_step0, (int64_t)0, (size_t)(n_tiles + 1), rocprim::plus<int64_t>(), s));
+        char *tmp = B.get<char>(b_scan);
+        PLAN_CHECK(B.e);
+        for (int64_t *arr : {p->tile_step0, p->tile_quad0, p->tile_ext0}) {
+            size_t bb = b_scan;
+            PLAN_CHECK(rocprim::exclusive_scan(tmp, bb, arr, arr, (int64_t)0, (size_t)(n_tiles + 1), rocprim::plus<int64_t>(), s));
+        }
+    }
+    std::vector<int64_t> h_pos0((size_t)n_tiles + 1);
+    PLAN_CHECK(hipMemcpyAsync(&p->n_steps, p->tile_step0 + n_tiles, 8, hipMemcpyDeviceToHost, s));
+    PLAN_CHECK(hipMemcpyAsync(&p->n_quads, p->tile_quad0 + n_tiles, 8, hipMemcpyDeviceToHost, s));
+    PLAN_CHECK(hipMemcpyAsync(&p->n_ext, p->tile_ext0 + n_tiles, 8, hipMemcpyDeviceToHost, s));
+    PLAN_CHECK(hipMemcpyAsync(h_pos0.data(), p->tile_slot0, 8 * h_pos0.size(), hipMemcpyDeviceToHost, s));
+    PLAN_CHECK(hipStreamSynchronize(s));
+    for (int64_t t = 0; t < n_tiles; ++t) p->max_rows = std::max(p->max_rows, (int)(h_pos0[(size_t)t + 1] - h_pos0[(size_t)t]));
+    PLAN_CHECK(hipMalloc(&p->step_desc, sizeof(int4) * (size_t)std::max<int64_t>(p->n_steps, 1)));
+    PLAN_CHECK(hipMalloc(&p->quad_code, sizeof(int4) * (size_t)std::max<int64_t>(p->n_quads, 1)));
+    PLAN_CHECK(hipMalloc(&p->quad_val, sizeof(double) * 4 * (size_t)std::max<int64_t>(p->n_quads, 1)));
+    PLAN_CHECK(hipMalloc(&p->ext_src, 4 * (size_t)std::max<int64_t>(p->n_ext, 4)));
+    a.step_desc = p->step_desc; a.quad_code = p->quad_code; a.quad_val = (double *)p->quad_val; a.ext_src = p->ext_src;
+    PLAN_CHECK(hipMemsetAsync(a.hash_key, 0xFF, 4 * (4 * (size_t)T->nnz + 4), s));
+    if (T->rp64) hipLaunchKernelGGL((plan_steps_kernel<int64_t, true>), dim3(grid_t), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((plan_steps_kernel<int32_t, true>), dim3(grid_t), dim3(64), 0, s, a);
+    PLAN_CHECK(hipGetLastError());
+    unsigned long long n_demoted = 0;
+    PLAN_CHECK(hipMemcpyAsync(&n_demoted, a.n_demoted, 8, hipMemcpyDeviceToHost, s));
+    PLAN_CHECK(hipStreamSynchronize(s));
+#undef PLAN_RP
+#undef PLAN_CHECK
+    if (getenv("BIS_TRSV_TILE_STATS"))
+        fprintf(stderr, "tiled sptrsv plan (%s): %lld rows, %d tiles (largest %d rows), %lld steps (%.1f rows per step), %lld quads (%.2f x the entries), "
+                        "%lld external ordinals (%.2f per row), %lld in-tile operands beyond the ring; grid tiles, skew %d %d %d; device plan\n",
+                backward ? "backward" : "forward", (long long)n, p->n_tiles, p->max_rows, (long long)p->n_steps,
+                (double)n / (double)std::max<int64_t>(p->n_steps, 1), (long long)p->n_quads, 4.0 * (double)p->n_quads / (double)T->nnz,
+                (long long)p->n_ext, (double)p->n_ext / (double)n, (long long)n_demoted, sa, sb, sc);
+    guard.p = nullptr;
+    *out = p;
+    return BIS_OK;
+}
+
+// trsv_tiled: -1 (default) the tiled sweep where the device plan applies (a valid grid hint); 1 also elsewhere (host
+// plan: interval tiles, seconds at 10^7 rows); 2 host plan always (the device plan's oracle in the tests); 0 never
+bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_tiled **out) {
+    *out = nullptr;
+    const int mode = bis_opts().trsv_tiled;
+    if (mode == 0) return BIS_OK;
+    if (mode != 2) {
+        const bis_status st = trsv_tiled_build_device(ctx, T, backward, out);
+        if (st != BIS_OK || *out) return st;
+    }
+    return mode > 0 ? trsv_tiled_build_host(ctx, T, backward, out) : BIS_OK;
 }
 
 bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, const double *D, const double *b) {

@@ -733,31 +733,46 @@ def test_sptrsv_wave_grid_is_capped_by_residency(ctx, oracle):
         ctx.set_option("trsv_grid", -1)
 
 
-@pytest.mark.parametrize("kind,size,rows,edge", [("anderson", 40, -1, 0), ("anderson", 40, 700, 0), ("hpcg", 32, -1, 0), ("hpcg", 32, 300, 0),
-                                                  ("fem", (14, 12, 10), -1, 0), ("fem", (14, 12, 10), 100, 0),
-                                                  ("anderson", 40, -1, -1), ("anderson", 40, -1, 5), ("hpcg", 32, -1, -1), ("hpcg", 32, -1, 6),
-                                                  ("fem", (14, 12, 10), -1, 4), ("fem", (14, 12, 10), -1, -1)])
-def test_tiled_sweep_bit_exact(ctx, oracle, kind, size, rows, edge):
-    """The opt-in tiled natural-order sweep (`trsv_tiled`, bis_trsv_tiled.hip: tiles solved by one workgroup each,
-    in-tile operands through LDS rings, external ones through a poller wave): same CRS-order fma chain per row as
-    the reference's serial loop -> bit-exact against the fma oracle, forward and backward, also with x aliasing b
-    (gmres.hpp:173) and with tiles much smaller than the default (every ring wraps, operands leave the own-result
-    ring and come back through the poller)."""
+def _tiled_cases():
+    sizes = {"anderson": 40, "hpcg": 32, "fem": (14, 12, 10)}
+    cases = []
+    for kind, rows in (("anderson", 700), ("hpcg", 300), ("fem", 100)):  # interval tiles of the natural order: host plan
+        cases += [(kind, sizes[kind], -1, 0, 1, 0), (kind, sizes[kind], rows, 0, 1, 0)]
+    for kind, edge in (("anderson", 5), ("hpcg", 6), ("fem", 4), ("hpcg", 5 | 3 << 8 | 2 << 16)):  # grid tiles: host (2) and device (-1) plan
+        for mode in (2, -1):
+            cases += [(kind, sizes[kind], -1, -1, mode, 0), (kind, sizes[kind], -1, edge, mode, 0)]
+    cases += [("hpcg", 32, -1, -1, -1, 1), ("fem", (14, 12, 10), -1, -1, -1, 1)]  # device plan over a 64-bit row_ptr
+    return cases
+
+
+@pytest.mark.parametrize("kind,size,rows,edge,mode,rp64", _tiled_cases())
+def test_tiled_sweep_bit_exact(ctx, oracle, capfd, monkeypatch, kind, size, rows, edge, mode, rp64):
+    """The tiled natural-order sweep (bis_trsv_tiled.hip: tiles solved by one workgroup each, in-tile operands
+    through LDS rings, external ones through a poller wave): same CRS-order fma chain per row as the reference's
+    serial loop -> bit-exact against the fma oracle, forward and backward, also with x aliasing b (gmres.hpp:173)
+    and with tiles much smaller than the default (every ring wraps, operands leave the own-result ring and come back
+    through the poller).  Its plan comes from the host (interval tiles, or grid tiles as the device plan's oracle) or
+    from the device (grid tiles, the default on generated matrices): the two must describe the same plan."""
     A = {"anderson": lambda: oracle.gen_anderson(size, shift=9.0), "hpcg": lambda: oracle.gen_hpcg(size),
          "fem": lambda: oracle.gen_fem(*size)}[kind]()
-    dA = {"anderson": lambda: ctx.gen_anderson(size, shift=9.0), "hpcg": lambda: ctx.gen_hpcg(size),
-          "fem": lambda: ctx.gen_fem(*size)}[kind]()
+    make = {"anderson": lambda: ctx.gen_anderson(size, shift=9.0), "hpcg": lambda: ctx.gen_hpcg(size),
+            "fem": lambda: ctx.gen_fem(*size)}[kind]
     n = A.n_rows
     L, Ls, U, Us = oracle.split_LU(A)
     D, _, _ = oracle.peel_diag(L)
     b = np.random.default_rng(17).uniform(-1, 1, n)
-    ctx.set_option("trsv_tiled", 1)
+    monkeypatch.setenv("BIS_TRSV_TILE_STATS", "1")
+    ctx.set_option("trsv_tiled", mode)
     ctx.set_option("trsv_tile_rows", rows)
     ctx.set_option("trsv_tile_edge", edge)
+    ctx.set_option("force_rp64", rp64)
     try:
+        dA = make()
         dLs, dUs, dD, dDinv = ctx.split_strict(dA)
+        assert dLs.rp_width == (8 if rp64 else 4)
         db, x = ctx.upload(b), ctx.alloc(n)
         want_f, want_b = oracle.sptrsv(Ls, D, b), oracle.sptrsv(Us, D, b, backward=True)
+        capfd.readouterr()
         for _ in range(2):  # the second sweep reuses the plan and the scratch
             ctx.sptrsv(dLs, x, dD, db)
             assert np.array_equal(x.to_host(), want_f)
@@ -767,10 +782,57 @@ def test_tiled_sweep_bit_exact(ctx, oracle, kind, size, rows, edge):
         ctx.sptrsv(dLs, x, dD, x)
         assert np.array_equal(x.to_host(), want_f)
         ctx.sync()
+        lines = [l for l in capfd.readouterr().err.splitlines() if l.startswith("tiled sptrsv plan")]
+        assert len(lines) == 2  # one plan per triangle, built once
+        if edge == 0:
+            assert all("interval tiles" in l for l in lines)
+        else:
+            assert all("grid tiles" in l and (("device plan" in l) == (mode == -1)) for l in lines)
+        if mode == -1 and not rp64:  # the host plan of the same triangles: same tiles, steps, quads, external ordinals
+            ctx.set_option("trsv_tiled", 2)
+            hLs, hUs, _, _ = ctx.split_strict(dA)
+            ctx.sptrsv(hLs, x, dD, db)
+            ctx.bsptrsv(hUs, x, dD, db)
+            ctx.sync()
+            host = [l for l in capfd.readouterr().err.splitlines() if l.startswith("tiled sptrsv plan")]
+            counts = lambda l: l.split(";")[0]
+            assert [counts(l) for l in host] == [counts(l) for l in lines]
     finally:
         ctx.set_option("trsv_tiled", -1)
         ctx.set_option("trsv_tile_rows", -1)
         ctx.set_option("trsv_tile_edge", -1)
+        ctx.set_option("force_rp64", -1)
+
+
+def test_tiled_sweep_grid_hint(ctx, oracle, capfd, monkeypatch):
+    """bis_mat_set_grid_hint on an uploaded matrix: a true hint gives the tiled sweep (device plan; pairs of x
+    neighbours read as two unknowns of one node are a true description too), a hint that does not describe the
+    pattern is found out by the plan's own checks (no admissible skew, or the order is not a linear extension) and
+    costs nothing but falling back to the level-scheduled kernels; the sweeps are bit-exact either way, and so is the
+    default without a hint."""
+    monkeypatch.setenv("BIS_TRSV_TILE_STATS", "1")
+    A = oracle.gen_hpcg(24)
+    n = A.n_rows
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    b = np.random.default_rng(23).uniform(-1, 1, n)
+    want_f, want_b = oracle.sptrsv(Ls, D, b), oracle.sptrsv(Us, D, b, backward=True)
+    db, x = ctx.upload(b), ctx.alloc(n)
+    for hint, tiled in (((24, 24, 24, 1), True), ((12, 24, 24, 2), True), ((48, 12, 24, 1), False), ((16, 36, 24, 1), None), (None, False)):
+        dA = ctx.matrix(A)
+        if hint:
+            dA.set_grid_hint(*hint)
+        dLs, dUs, dD, _ = ctx.split_strict(dA)
+        capfd.readouterr()
+        ctx.sptrsv(dLs, x, dD, db)
+        assert np.array_equal(x.to_host(), want_f)
+        ctx.bsptrsv(dUs, x, dD, db)
+        assert np.array_equal(x.to_host(), want_b)
+        ctx.sync()
+        lines = [l for l in capfd.readouterr().err.splitlines() if l.startswith("tiled sptrsv plan")]
+        assert tiled is None or len(lines) == (2 if tiled else 0), (hint, lines)
+    with pytest.raises(Exception):
+        ctx.matrix(A).set_grid_hint(24, 24, 23, 1)  # extents must multiply to the row count
 
 
 def _queue_order(A, rcm):
