@@ -38,6 +38,9 @@ static void run(Args *cli_args, Timers *timers) {
         }
         A->upload();
     }
+    if (cli_args->grid_hint[0] > 0)
+        bis::check(bis_mat_set_grid_hint(A->dev, cli_args->grid_hint[0], cli_args->grid_hint[1], cli_args->grid_hint[2], (int)cli_args->grid_hint[3]),
+                   "-grid (the extents must multiply to the number of rows)");
     TIME(timers, "preprocessing", preprocessing(cli_args, solver, timers, A))
     TIME(timers, "solve", solve(cli_args, solver, timers))
     TIME(timers, "postprocessing", postprocessing(cli_args, solver, timers))
@@ -49,7 +52,7 @@ int main(int argc, char *argv[]) {
     Args cli_args;
     parse_cli(&cli_args, argc, argv);
     bis::init(cli_args.device);
-    if (cli_args.trsv_tiled) bis_set_option("trsv_tiled", 1);
+    if (cli_args.trsv_mode >= 0) bis_set_option("trsv_tiled", cli_args.trsv_mode);
     TIME(&timers, "total", run(&cli_args, &timers))
     print_timers(&cli_args, &timers);
     bis::shutdown();

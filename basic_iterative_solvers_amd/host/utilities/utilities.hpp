@@ -61,7 +61,16 @@ inline void parse_cli(Args *a, int argc, char *argv[]) {
         else if (arg == "-rl" && i + 1 < argc) a->restart_length = atoi(argv[++i]);
         else if (arg == "-unfused") a->unfused = true;
         else if (arg == "-hostscalars") a->host_scalars = true;
-        else if (arg == "-trsv" && i + 1 < argc) a->trsv_tiled = std::string(argv[++i]) == "tiled";
+        else if (arg == "-trsv" && i + 1 < argc) {
+            const std::string m = argv[++i];
+            a->trsv_mode = m == "tiled" ? 1 : m == "level" ? 0 : -1;
+        } else if (arg == "-grid" && i + 1 < argc) {
+            a->grid_hint[3] = 1;
+            if (sscanf(argv[++i], "%lld,%lld,%lld,%lld", &a->grid_hint[0], &a->grid_hint[1], &a->grid_hint[2], &a->grid_hint[3]) < 3) {
+                fprintf(stderr, "ERROR: -grid NX,NY,NZ[,DOF]\n");
+                exit(EXIT_FAILURE);
+            }
+        }
         else if (arg == "-perm" && i + 1 < argc) a->perm_mode = argv[++i];
         else if (arg == "-dump-perm" && i + 1 < argc) a->dump_perm = argv[++i];
         else if (arg == "-dump-x" && i + 1 < argc) a->dump_x = argv[++i];

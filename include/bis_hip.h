@@ -84,7 +84,11 @@ BIS_API bis_status bis_device_info(bis_ctx *ctx, char *arch, size_t arch_len,
                                    int *n_cus, int64_t *hbm_bytes);
 /* Tuning knobs, process-wide: "spmv_variant", "spmv_window", "spmv_chunk",
  * "trsv_grid" (-1 = default), "force_rp64" (1: 64-bit row pointers at any
- * size).  Matrices created afterwards pick them up. */
+ * size), "trsv_tiled" (natural-order triangular sweeps: -1 = the tiled sweep
+ * where its plan can be built on the device, i.e. on matrices with a grid
+ * hint; 1 = also elsewhere, with the host-built plan; 0 = level-scheduled
+ * kernels only; 2 = host-built plan only, for tests).  Matrices created
+ * afterwards pick them up. */
 BIS_API bis_status bis_set_option(const char *name, int value);
 /* number of exported kernel-level symbols, for the load test */
 BIS_API int bis_abi_version(void);

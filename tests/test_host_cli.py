@@ -253,3 +253,37 @@ def test_cli_device_and_host_rcm_bfs_agree(tmp_path, mode, name, solver, pc, sca
     assert np.array_equal(np.loadtxt(f1, dtype=np.int64), np.loadtxt(f2, dtype=np.int64))
     assert a["iters"] == b["iters"] and len(a["hist"]) == len(b["hist"])
     assert np.max(np.abs(a["hist"] - b["hist"])) <= 1e-12 * a["hist"][0]
+
+
+@pytest.mark.parametrize("solver,pc", [("cg", "sgs"), ("gm", "gs"), ("bi", "ilu0"), ("gs", "none")])
+def test_cli_grid_hint_and_trsv_modes(tmp_path, oracle, monkeypatch, solver, pc):
+    """-grid NX,NY,NZ[,DOF] tells the triangular sweeps that a matrix read from a file is a stencil on a grid (here
+    the 27-point pattern on 12 x 13 x 14 written as general MatrixMarket): they then run tiled (plan built on the
+    device), and since every row keeps the reference's CRS-order fma chain (kernels.hpp:54-107) the printed residual
+    table is the same, digit for digit, as with the level-scheduled kernels (-trsv level) and as without the hint.
+    A generated matrix carries the hint by itself."""
+    monkeypatch.setenv("BIS_TRSV_TILE_STATS", "1")
+    A = oracle.gen_hpcg(12, 13, 14)
+    mtx = str(tmp_path / "grid.mtx")
+    with open(mtx, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (A.n_rows, A.n_rows, len(A.col)))
+        rows = np.repeat(np.arange(A.n_rows), np.diff(A.row_ptr))
+        for r, c, v in zip(rows, A.col, A.val):
+            f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
+
+    def run(matrix, extra):
+        cmd = [BIN, matrix, "-" + solver] + (["-p", pc] if pc != "none" else []) + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return RES.findall(out.stdout), out.stderr.count("tiled sptrsv plan"), out.stderr.count("device plan")
+
+    plain, n_plain, _ = run(mtx, [])
+    hinted, n_hinted, n_dev = run(mtx, ["-grid", "12,13,14"])
+    level, n_level, _ = run(mtx, ["-grid", "12,13,14", "-trsv", "level"])
+    assert len(plain) > 3 and plain == hinted == level
+    assert n_plain == 0 and n_level == 0 and n_hinted >= 1 and n_dev == n_hinted
+    gen, n_gen, n_gen_dev = run("hpcg:12,13,14", [])
+    gen_level, n_gl, _ = run("hpcg:12,13,14", ["-trsv", "level"])
+    assert gen == gen_level == plain and n_gen >= 1 and n_gen_dev == n_gen and n_gl == 0
+    bad = subprocess.run([BIN, mtx, "-cg", "-grid", "12,13,13"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "-grid" in bad.stderr

@@ -1,4 +1,4 @@
-# BASELINE configs 2-5 through the host CLI (full sizes): natural order (level-scheduled and tiled sweeps), multi-colour,
+# BASELINE configs 2-5 through the host CLI (full sizes): natural order (tiled sweeps, the default on these generated matrices, and level-scheduled ones), multi-colour,
 # device- against host-scalar GMRES / BiCGSTAB.  BIS_TIMERS_SYNC=0: the timer tree does not drain the stream per call.
 B=$GRAFT_REPO_ROOT/basic_iterative_solvers_amd/host/basic_iterative_solvers
 O=$GRAFT_REPO_ROOT/gpurun_out/configs.log
@@ -9,19 +9,19 @@ run anderson:256 -cg
 run anderson:256,shift=9 -cg -p j
 run anderson:256,shift=9 -gm -p gs
 run anderson:256,shift=9 -gm -p gs -hostscalars
-run anderson:256,shift=9 -gm -p gs -trsv tiled
+run anderson:256,shift=9 -gm -p gs -trsv level
 run anderson:256,shift=9 -gm -p gs -perm mc
 run anderson:256,shift=9 -gm -p gs -perm rcm
 run fem:80,80,81 -bi -p ilu0
 run fem:80,80,81 -bi -p ilu0 -hostscalars
-run fem:80,80,81 -bi -p ilu0 -trsv tiled
+run fem:80,80,81 -bi -p ilu0 -trsv level
 run fem:80,80,81 -bi -p ilu0 -perm mc
 run fem:80,80,81 -cg -p j
 run hpcg:256 -cg -p sgs -perm mc
 run hpcg:128 -cg -p sgs
-run hpcg:128 -cg -p sgs -trsv tiled
+run hpcg:128 -cg -p sgs -trsv level
 run anderson:256,shift=9 -gs
-run anderson:256,shift=9 -gs -trsv tiled
+run anderson:256,shift=9 -gs -trsv level
 export BIS_TIMERS_SYNC=1
 run anderson:256,shift=9 -gm -p gs
 run fem:80,80,81 -bi -p ilu0
