@@ -76,6 +76,7 @@ struct bis_options {
     int spmv_packed32 = -1; // 1: also try the 32-window packed format (opt-in)
     int spmv_lds_pad = -1; // diagnostic: extra dynamic LDS bytes per workgroup (lowers occupancy)
     int spmv_packed = -1;  // 16-bit packed column stream: 0 off, 1 select tree, 2 lane permute (-1: default = 1)
+    int spmv_valdict = -1; // value dictionary (a matrix with <= 256 distinct values streams 1-byte value codes): 0 off (-1: default = on)
     int dist_host_plan = -1; // 1: bis_dist_create plans the halo on the host from the downloaded structure (default: on the device)
     int trsv_tiled = -1;    // natural-order sweeps: -1 = tiled sweep (bis_trsv_tiled.hip) where its device plan applies (grid hint), 1 = also with the host plan, 2 = host plan only, 0 = level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
@@ -122,6 +123,13 @@ struct bis_mat {
     int64_t pk_base[2] = {0, 0};
     int pk_state[2] = {0, 0};
     int pk_kind[2] = {0, 0};   // 1: 8 windows x 8192 columns, 3: 32 windows x 2048 columns
+    // value dictionary (bis_spmv.hip): a matrix with at most 256 distinct values (compared bit for bit) keeps them in a
+    // 256-entry table and streams one byte per non-zero instead of the 8-byte value.  Built lazily at the first SpMV;
+    // state 0 = not tried, 1 = usable, -1 = too many distinct values.  The CRS values stay authoritative.
+    uint8_t *vcode = nullptr;  // [nnz_range + pad], index k - vd_base
+    double *vdict = nullptr;   // [256], ascending bit patterns, unused entries 0
+    int64_t vd_base = 0;
+    int vd_state = 0, vd_n = 0;
     // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
     int32_t *blkf_row = nullptr;
     int64_t *blkf_nnz = nullptr;
@@ -248,6 +256,8 @@ bis_status bis_mat_alloc(bis_ctx *ctx, int64_t n_rows, int64_t n_cols,
 bis_status bis_mat_finalize(bis_ctx *ctx, bis_mat *A);
 bis_status bis_spmv_build_window(bis_ctx *ctx, bis_mat *A);
 void bis_spmv_drop_packed(bis_mat *A);
+void bis_spmv_drop_valdict(bis_mat *A); // after the values of A changed in place
+bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A);
 // try to build the packed-column stream of table t (0 plain, 1 fused); A->pk_state[t] tells the outcome
 bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t);
 // free row-block tables, packed streams and window structures (not the CRS arrays)

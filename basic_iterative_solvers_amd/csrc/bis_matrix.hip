@@ -403,6 +403,7 @@ void bis_mat_free_meta(bis_mat *A) {
     A->blk_row = A->blkf_row = nullptr;
     A->blk_nnz = A->blkf_nnz = nullptr;
     bis_spmv_drop_packed(A);
+    bis_spmv_drop_valdict(A);
     hipFree(A->loc); hipFree(A->tiles); hipFree(A->tile_cnt);
     A->loc = nullptr; A->tiles = nullptr; A->tile_cnt = nullptr;
     A->win_ok = false;

@@ -34,7 +34,9 @@
 // 93 % of the streaming rate in fabric bytes) and the tuning record: DESIGN.md 4.
 #include "bis_internal.hpp"
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -278,6 +280,155 @@ __global__ __launch_bounds__(256) void spmv_wave_per_row_kernel(
 
 
 // ---------------------------------------------------------------------------
+// Value-dictionary variant.  A matrix with at most 256 distinct values (any
+// constant-coefficient stencil: HPCG has two) keeps them in a 256-entry table;
+// per non-zero the kernel streams a 2-byte column code and a 1-byte value code
+// -- 3 instead of CRS's 12 bytes -- and takes the value from an LDS copy of the
+// table.  The values are the CRS ones bit for bit, products, their order and
+// the row sums are those of spmv_rowblock_kernel: same results to the last bit.
+// The CRS arrays stay authoritative (download, split, triangular solves use
+// them).  With a quarter of the bytes the kernel is no longer HBM-bound: what
+// counts is the number of wave instructions and of L1 tag lookups per non-zero
+// (profiles/r02_g_spmv_pmc_*), hence the form below.
+// ---------------------------------------------------------------------------
+
+// acc += prod[a] + ... + prod[z - 1], left to right (the reference's summation order), the LDS reads issued eight at a time
+__device__ __forceinline__ void acc_row(const double *prod, int a, int z, double &acc) {
+    int j = a;
+    for (; j + 8 <= z; j += 8) {
+        double p[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p[q] = prod[j + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += p[q];
+    }
+    for (; j < z; ++j) acc += prod[j];
+}
+
+// Consecutive form: lane t of the workgroup takes non-zeros s + j*256 + t, so one gather instruction covers 64
+// CONSECUTIVE non-zeros (2-3 rows of a stencil), the narrow stream loads (2 B + 1 B per lane) are fully coalesced, and
+// the column window base comes from one cross-lane permute (lane j < 8 of every wave holds base j) instead of the
+// select tree: 159 M vector-ALU wave instructions per HPCG-256 launch against 273 M for the 4-non-zeros-per-lane form
+// with the select tree (0.62 against 0.70 ms; a persistent, software-pipelined variant of this form: 0.71 ms).
+template <typename RP, int MODE>
+__global__ __launch_bounds__(256) void spmv_rowblock_vd_kernel(
+    const RP *__restrict__ row_ptr, const double *x, double *y, const int32_t *__restrict__ blk_row,
+    const int64_t *__restrict__ blk_nnz, int n_blocks, int n_blocks_pad8, const double *w, double *partials,
+    const uint16_t *__restrict__ pk, int64_t pk_base, const int32_t *__restrict__ seg_base, int col_max, const int *stop,
+    const uint8_t *__restrict__ vcode, int64_t vd_base, const double *__restrict__ vdict) {
+    constexpr int T = 256, J = 8;
+    constexpr bool FUSE_DOT = MODE == 1;
+    if (MODE == 1 && stop && stop[1]) return;
+    extern __shared__ __attribute__((aligned(16))) double prod[];
+    __shared__ double dict[256];
+    const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8)
+                                    : (n_blocks_pad8 < -1 ? xcd_group_remap(blockIdx.x, -n_blocks_pad8) : (int)blockIdx.x);
+    if (b >= n_blocks) return;
+    dict[threadIdx.x] = vdict[threadIdx.x];
+    const int r0 = blk_row[b], r1 = blk_row[b + 1];
+    const int64_t s = blk_nnz[b], e = blk_nnz[b + 1];
+    const int my_r = r0 + (int)threadIdx.x;
+    RP rp_a = 0, rp_z = 0;
+    if (my_r < r1) { rp_a = row_ptr[my_r]; rp_z = row_ptr[my_r + 1]; }
+    const int lane_base = seg_base[(size_t)b * 8 + (threadIdx.x & 7)];
+    const char *xb = reinterpret_cast<const char *>(x);
+    const uint16_t *pkp = pk + (s - pk_base);
+    const uint8_t *vcp = vcode + (s - vd_base);
+    const int n = (int)(e - s);
+    __syncthreads();
+    for (int base = 0; base < n; base += J * T) {
+        unsigned cc[J], vc[J];
+        double xx[J], vv[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const unsigned idx = (unsigned)min(base + j * T + (int)threadIdx.x, n - 1); // 32-bit offsets: scalar base + vector offset addressing
+            cc[j] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(pkp) + (idx << 1));
+            vc[j] = *(vcp + idx);
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int wbase = __builtin_amdgcn_ds_bpermute((int)((cc[j] >> (kPkOffBits - 2)) & 28u), lane_base);
+            xx[j] = x_at<false>(xb, wbase + (int)(cc[j] & (kPkSpan - 1)));
+            vv[j] = dict[vc[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int idx = base + j * T + (int)threadIdx.x;
+            double pr = vv[j] * xx[j];
+            asm volatile("" : "+v"(pr));
+            if (idx < n) prod[idx] = pr;
+        }
+    }
+    __syncthreads();
+    double dot_acc = 0.0;
+    for (int r = my_r; r < r1; r += T) {
+        if (r != my_r) { rp_a = row_ptr[r]; rp_z = row_ptr[r + 1]; }
+        const int a = (int)((int64_t)rp_a - s), z = (int)((int64_t)rp_z - s);
+        double acc = 0.0;
+        acc_row(prod, a, z, acc);
+        if (MODE == 2) y[r] = (w[r] - acc) / partials[r];
+        else y[r] = acc;
+        if (FUSE_DOT) dot_acc = fma(acc, w[r], dot_acc);
+    }
+    if (FUSE_DOT) {
+        const double t = wave_sum(dot_acc);
+        if ((threadIdx.x & 63) == 0) partials[(size_t)b * (T / 64) + (threadIdx.x >> 6)] = t;
+    }
+}
+
+// distinct values of val[s, e), one list per wave (a workgroup is one wave): lists[w * 257] = count (257 = more than
+// 256, *overflow is raised and every wave stops), then the values' bit patterns
+__global__ __launch_bounds__(64) void vd_collect_kernel(const double *__restrict__ val, int64_t s, int64_t e,
+                                                        unsigned long long *__restrict__ lists, int *overflow) {
+    __shared__ unsigned long long list[256];
+    const int lane = threadIdx.x;
+    int n = 0;
+    for (int64_t k0 = s + (int64_t)blockIdx.x * 64; k0 < e && n <= 256; k0 += (int64_t)gridDim.x * 64) {
+        if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { n = 257; break; }
+        const int64_t k = k0 + lane;
+        const unsigned long long v = k < e ? (unsigned long long)__double_as_longlong(val[k]) : 0ull;
+        bool found = k >= e;
+        for (int j = 0; j < n && __ballot(!found); ++j) found |= list[j] == v;
+        while (const unsigned long long open = __ballot(!found)) {
+            const int leader = (int)__builtin_ctzll(open);
+            const unsigned long long lv = __shfl(v, leader);
+            if (n == 256) { n = 257; break; }
+            if (lane == 0) list[n] = lv;
+            ++n;
+            found |= v == lv;
+        }
+        __syncthreads(); // one wave: orders the list writes before the next round's reads
+    }
+    if (n > 256 && lane == 0) atomicExch(overflow, 1);
+    if (lane == 0) lists[(size_t)blockIdx.x * 257] = (unsigned long long)n;
+    for (int j = lane; j < n && j < 256; j += 64) lists[(size_t)blockIdx.x * 257 + 1 + j] = list[j];
+}
+
+// vcode[k - base] = index of val[k] in the (ascending) dictionary; four codes per thread, one 32-bit store
+__global__ __launch_bounds__(256) void vd_encode_kernel(const double *__restrict__ val, int64_t s, int64_t e, int64_t base,
+                                                        const double *__restrict__ vdict, int n_dict, uint8_t *__restrict__ vcode) {
+    __shared__ unsigned long long dict[256];
+    dict[threadIdx.x] = (unsigned long long)__double_as_longlong(vdict[threadIdx.x]);
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t k4 = base + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; k4 < e; k4 += stride) {
+        unsigned packed = 0;
+        for (int q = 0; q < 4; ++q) {
+            const int64_t k = k4 + q;
+            if (k < s || k >= e) continue;
+            const unsigned long long v = (unsigned long long)__double_as_longlong(val[k]);
+            int lo = 0, hi = n_dict - 1; // the value is in the table
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (dict[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            packed |= (unsigned)lo << (8 * q);
+        }
+        *reinterpret_cast<unsigned *>(vcode + (k4 - base)) = packed;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // x-window variant.  Analysis (once per matrix): for every row block, the
 // sorted list of the 16-column tiles of x its non-zeros reference (<= 128
 // tiles) and, per non-zero, a 16-bit offset into that window.  The SpMV then
@@ -488,6 +639,7 @@ struct SpmvArgs {
     const uint16_t *pk = nullptr; int64_t pk_base = 0; const int32_t *seg_base = nullptr; int col_max = 0; int pk_mode = 0;
     bool wide = false; // 2^29 columns or more: 64-bit x addressing, 32-bit column stream
     const int *stop = nullptr;
+    const uint8_t *vcode = nullptr; int64_t vd_base = 0; const double *vdict = nullptr; // value dictionary (pk_mode 1 only)
 };
 
 template <typename RP, int T, int U, int BR = 0>
@@ -513,8 +665,21 @@ void launch_variant(const SpmvArgs &a) {
 
 // variant id: 10/20/40 = 256 threads with U = 1/2/4 staged vectors per lane
 // (tuning knob BIS_SPMV_VARIANT)
+template <typename RP, int MODE>
+void launch_vd(const SpmvArgs &a) {
+    hipLaunchKernelGGL((spmv_rowblock_vd_kernel<RP, MODE>), dim3(a.grid), dim3(256), a.lds_bytes, a.stream,
+                       (const RP *)a.row_ptr, a.x, a.y, a.blk_row, a.blk_nnz, a.nb, a.remap_arg, a.w, a.partials, a.pk,
+                       a.pk_base, a.seg_base, a.col_max, a.stop, a.vcode, a.vd_base, a.vdict);
+}
+
 template <typename RP>
 bool launch_by_id(int id, const SpmvArgs &a) {
+    if (a.vcode && id == 20 && a.pk_mode == 1) { // value dictionary: the default form only
+        if (a.mode == 2) launch_vd<RP, 2>(a);
+        else if (a.mode == 1) launch_vd<RP, 1>(a);
+        else launch_vd<RP, 0>(a);
+        return true;
+    }
     switch (id) {
     case 10: launch_variant<RP, 256, 1>(a); return true;
     case 20: launch_variant<RP, 256, 2>(a); return true;
@@ -608,6 +773,73 @@ void bis_spmv_drop_packed(bis_mat *A) {
     }
 }
 
+void bis_spmv_drop_valdict(bis_mat *A) {
+    hipFree(A->vcode); hipFree(A->vdict);
+    A->vcode = nullptr; A->vdict = nullptr; A->vd_state = 0; A->vd_n = 0;
+}
+
+static int spmv_valdict_mode() { return bis_opts().spmv_valdict < 0 ? 1 : bis_opts().spmv_valdict; }
+
+bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
+    if (A->vd_state != 0) return BIS_OK;
+    A->vd_state = -1;
+    if (A->nnz == 0 || A->n_blocks == 0) return BIS_OK;
+    int64_t ends[2];
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[0], A->blk_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[1], A->blk_nnz + A->n_blocks, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t s = ends[0], e = ends[1];
+    if (e <= s) return BIS_OK;
+    const int n_waves = (int)std::min<int64_t>((e - s + 63) / 64, (int64_t)ctx->n_cus * 8);
+    unsigned long long *lists = nullptr;
+    int *overflow = (int *)ctx->counters + 46;
+    BIS_HIP_CHECK(ctx, hipMalloc(&lists, sizeof(unsigned long long) * 257 * (size_t)n_waves));
+    hipError_t he = hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(vd_collect_kernel, dim3(n_waves), dim3(64), 0, ctx->stream, A->val, s, e, lists, overflow);
+        he = hipGetLastError();
+    }
+    std::vector<unsigned long long> h((size_t)257 * n_waves);
+    int h_over = 0;
+    if (he == hipSuccess) he = hipMemcpyAsync(&h_over, overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(h.data(), lists, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    hipFree(lists);
+    BIS_HIP_CHECK(ctx, he);
+    if (h_over) return BIS_OK;
+    std::vector<unsigned long long> all;
+    for (int w = 0; w < n_waves; ++w) {
+        const size_t n = (size_t)h[(size_t)w * 257];
+        if (n > 256) return BIS_OK;
+        all.insert(all.end(), h.begin() + (size_t)w * 257 + 1, h.begin() + (size_t)w * 257 + 1 + n);
+    }
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    if (all.empty() || all.size() > 256) return BIS_OK;
+    unsigned long long table[256] = {};
+    std::copy(all.begin(), all.end(), table);
+    A->vd_base = s & ~(int64_t)3;
+    const size_t n_code = (size_t)(e - A->vd_base) + 16;
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->vdict, sizeof table));
+    he = hipMalloc(&A->vcode, n_code);
+    if (he == hipSuccess) he = hipMemsetAsync(A->vcode, 0, n_code, ctx->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(A->vdict, table, sizeof table, hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) {
+        const int grid = (int)std::min<int64_t>((e - A->vd_base + 1023) / 1024, (int64_t)ctx->n_cus * 32);
+        hipLaunchKernelGGL(vd_encode_kernel, dim3(grid), dim3(256), 0, ctx->stream, A->val, s, e, A->vd_base, A->vdict, (int)all.size(), A->vcode);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream); // table[] lives on this stack frame
+    if (he != hipSuccess) {
+        bis_spmv_drop_valdict(A);
+        A->vd_state = -1;
+        BIS_HIP_CHECK(ctx, he);
+    }
+    A->vd_n = (int)all.size();
+    A->vd_state = 1;
+    return BIS_OK;
+}
+
 // default: select tree (see the tuning record in DESIGN.md section 4)
 static int spmv_packed_mode() { return bis_opts().spmv_packed < 0 ? 1 : bis_opts().spmv_packed; }
 
@@ -666,6 +898,10 @@ static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArg
         a->pk = A->pk[t]; a->pk_base = A->pk_base[t]; a->seg_base = A->pk_seg[t];
         a->col_max = (int)std::max<int64_t>(A->n_cols - 1, 0);
         a->pk_mode = A->pk_kind[t] == 3 ? 3 : (spmv_packed_mode() == 2 ? 2 : 1);
+    }
+    if (a->pk_mode == 1 && spmv_valdict_mode()) { // the value dictionary rides on the packed column stream
+        if (bis_status st = bis_spmv_try_valdict(ctx, A)) return st;
+        if (A->vd_state == 1) { a->vcode = A->vcode; a->vd_base = A->vd_base; a->vdict = A->vdict; }
     }
     return BIS_OK;
 }
@@ -765,6 +1001,20 @@ bis_status bis_spmv(bis_ctx *ctx, const bis_mat *A, const double *x, double *y) 
     BIS_REQUIRE(ctx, A && (A->n_rows == 0 || (x && y)), "bis_spmv: bad arguments");
     BIS_REQUIRE(ctx, x != y, "bis_spmv: x and y must not alias");
     return bis_spmv_launch(ctx, A, x, y, nullptr, nullptr);
+}
+
+bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_bytes, int *val_bytes, int *n_dict) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A, "bis_mat_spmv_stream_info: bad arguments");
+    SpmvArgs a{};
+    const int64_t lds_doubles = (int64_t)A->chunk_nnz + A->max_row_nnz + 8;
+    if (A->n_rows > 0 && sizeof(double) * (size_t)lds_doubles <= 64 * 1024 && !(A->win_ok && spmv_window_mode()))
+        if (bis_status st = ensure_packed(ctx, A, 0, &a)) return st;
+    const bool vd = a.vcode && spmv_variant(a) == 20 && a.pk_mode == 1;
+    if (col_bytes) *col_bytes = a.pk_mode ? 2 : 4;
+    if (val_bytes) *val_bytes = vd ? 1 : 8;
+    if (n_dict) *n_dict = vd ? A->vd_n : 0;
+    return BIS_OK;
 }
 
 bis_status bis_compute_residual(bis_ctx *ctx, const bis_mat *A, const double *x, const double *b,

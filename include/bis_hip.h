@@ -83,6 +83,7 @@ BIS_API void *bis_ctx_stream(bis_ctx *ctx);
 BIS_API bis_status bis_device_info(bis_ctx *ctx, char *arch, size_t arch_len,
                                    int *n_cus, int64_t *hbm_bytes);
 /* Tuning knobs, process-wide: "spmv_variant", "spmv_window", "spmv_chunk",
+ * "spmv_valdict" (0: no value dictionary, see bis_mat_spmv_stream_info),
  * "trsv_grid" (-1 = default), "force_rp64" (1: 64-bit row pointers at any
  * size), "trsv_tiled" (natural-order triangular sweeps: -1 = the tiled sweep
  * where its plan can be built on the device, i.e. on matrices with a grid
@@ -126,6 +127,18 @@ BIS_API bis_status bis_mat_info(const bis_mat *A, int64_t *n_rows,
  * bis_set_option("force_rp64", 1) was in effect when the matrix was made (the
  * tests run the 64-bit instantiations at small sizes that way). */
 BIS_API int bis_mat_rp_width(const bis_mat *A);
+/* What the SpMV streams per non-zero for this matrix (decided, and built, at
+ * the first call of this function or of bis_spmv): col_bytes 4 (CRS columns) or
+ * 2 (packed 16-bit column codes); val_bytes 8 (CRS values) or 1 (value
+ * dictionary: the matrix has n_dict <= 256 distinct values, compared bit for
+ * bit -- every constant-coefficient stencil -- which the kernel keeps in LDS and
+ * indexes with a 1-byte code per non-zero; n_dict = 0 without a dictionary).
+ * Both are lossless re-encodings of the CRS arrays, which stay authoritative:
+ * same products, same summation order, bit-identical y.  Option
+ * "spmv_valdict" 0 switches the dictionary off. */
+BIS_API bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A,
+                                            int *col_bytes, int *val_bytes,
+                                            int *n_dict);
 /* Structured-grid hint: the rows are the unknowns of an nx x ny x nz grid, x
  * fastest, dof unknowns per node (row = ((z*ny + y)*nx + x)*dof + d) -- e.g.
  * an HPCG-n.mtx read from a file.  The generators set it themselves; strict

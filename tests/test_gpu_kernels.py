@@ -934,3 +934,106 @@ def test_fused_cg_general_preconditioner_vs_reference(ctx, key):
     iters, conv, hist = cg.status()
     check_history(dict(hist=hist, iters=iters, converged=conv), e, "cg")
     cg.free()
+
+
+def _few_values_matrix(rng, n, n_values, empty_head=0):
+    """Random pattern (ragged, unsorted, duplicates allowed, `empty_head` leading empty rows) whose values are drawn
+    from `n_values` distinct bit patterns, among them -0.0, 0.0, a denormal and both infinities' neighbours."""
+    lens = rng.integers(0, 40, n)
+    lens[:empty_head] = 0
+    lens[::53] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    col = rng.integers(0, n, rp[-1]).astype(np.int32)
+    special = np.array([-0.0, 0.0, 5e-324, -1.0, 26.0, 1.7976931348623157e308, -1.7976931348623157e308, 1.0 + 2.0 ** -52])
+    pool = np.concatenate([special, rng.uniform(-3, 3, max(n_values - len(special), 0))])[:n_values]
+    assert len(np.unique(pool.view(np.uint64))) == n_values
+    val = pool[rng.integers(0, n_values, rp[-1])]
+    val[:n_values] = pool  # every value occurs
+    return CRS(n, rp, col, val)
+
+
+@pytest.mark.parametrize("rp64", [0, 1])
+@pytest.mark.parametrize("form", [1])
+def test_spmv_value_dictionary(ctx, oracle, form, rp64):
+    """Matrices with at most 256 distinct values (compared bit for bit) stream 1-byte value codes against a
+    dictionary held in LDS (bis_mat_spmv_stream_info): a lossless re-encoding -- y is BIT-IDENTICAL to the kernel that
+    streams the CRS values (same products, same summation order) and within the kernel tolerance of the oracle's
+    kernels.hpp:22-52 loop.  2, 256 and 257 distinct values; blocks of
+    empty rows; 64-bit row pointers; a matrix whose values change in place (-scale) drops its dictionary."""
+    rng = np.random.default_rng(40 + form)
+    ctx.set_option("force_rp64", rp64)
+    try:
+        cases = [("hpcg", oracle.gen_hpcg(12, 10, 9), 2), ("anderson W=0", oracle.gen_anderson(9, W=0.0, shift=7.0), 2),
+                 ("256 values", _few_values_matrix(rng, 9000, 256, empty_head=5000), 256),
+                 ("257 values", _few_values_matrix(rng, 3000, 257), 0),
+                 ("fem", oracle.gen_fem(5, 4, 3), None)]
+        for name, A, want_dict in cases:
+            x = rng.uniform(-1, 1, A.n_cols)
+            ys = {}
+            for mode in (0, form):
+                ctx.set_option("spmv_valdict", mode)
+                dA = ctx.matrix(A)
+                col_b, val_b, n_dict = dA.spmv_stream_info()
+                if mode == 0:
+                    assert (val_b, n_dict) == (8, 0)
+                elif want_dict is not None and col_b == 2:
+                    assert (val_b, n_dict) == ((1, want_dict) if want_dict else (8, 0)), name
+                dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
+                ctx.spmv(dA, dx, dy)
+                ys[mode] = dy.to_host()
+                dA.free(); dx.free(); dy.free()
+            assert np.array_equal(ys[0], ys[form], equal_nan=True), name
+            if name != "256 values" and name != "257 values":  # (their huge values overflow to inf/nan in both)
+                yo = oracle.spmv(A, x)
+                scale = np.abs(A.to_scipy()).dot(np.abs(x)).max()
+                assert np.max(np.abs(ys[form] - yo)) <= KTOL * scale, name
+        # in-place scaling after the dictionary was built
+        ctx.set_option("spmv_valdict", form)
+        A = oracle.gen_hpcg(8)
+        dA = ctx.matrix(A)
+        x = rng.uniform(-1, 1, A.n_rows)
+        dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
+        ctx.spmv(dA, dx, dy)
+        assert dA.spmv_stream_info()[1:] == (1, 2)
+        s = ctx.scale_sym(dA)
+        ctx.spmv(dA, dx, dy)
+        sv = s.to_host()
+        B = CRS(A.n_rows, A.row_ptr, A.col, A.val * sv[np.repeat(np.arange(A.n_rows), np.diff(A.row_ptr))] * sv[A.col])
+        yo = oracle.spmv(B, x)
+        assert np.max(np.abs(dy.to_host() - yo)) <= KTOL * np.abs(B.to_scipy()).dot(np.abs(x)).max()
+    finally:
+        ctx.set_option("spmv_valdict", -1)
+        ctx.set_option("force_rp64", -1)
+
+
+@pytest.mark.parametrize("form", [1])
+def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form):
+    """The dictionary kernel's other two epilogues: the fused (Ap, p) of the CG schedule (bis_cg.hip) and the
+    triangular-sweep step on a colour block of a multi-coloured matrix -- residual history and sweep results are
+    bit-identical to the ones computed from the streamed CRS values."""
+    A = oracle.gen_hpcg(16)
+    n = A.n_rows
+    out = {}
+    try:
+        for mode in (0, form):
+            ctx.set_option("spmv_valdict", mode)
+            dA = ctx.gen_hpcg(16)
+            b, x = ctx.alloc(n), ctx.alloc(n)
+            ctx.init_vector(b, 1.0); ctx.init_vector(x, 0.1)
+            cg = ctx.cg(dA, b, x)
+            cg.init(0.0)
+            cg.iterate(25)
+            iters, conv, hist = cg.status(hist_cap=64)
+            B, perm, n_col = ctx.multicolour(dA)
+            Ls, Us, D, Dinv = ctx.split_strict(B)
+            rhs = ctx.upload(np.random.default_rng(3).uniform(-1, 1, n))
+            xf, xb = ctx.alloc(n), ctx.alloc(n)
+            ctx.sptrsv(Ls, xf, D, rhs)
+            ctx.bsptrsv(Us, xb, D, rhs)
+            out[mode] = (np.array(hist), x.to_host(), xf.to_host(), xb.to_host(), dA.spmv_stream_info())
+            cg.free()
+        assert out[0][4][1:] == (8, 0) and out[form][4][1:] == (1, 2)
+        for k in range(4):
+            assert np.array_equal(out[0][k], out[form][k]), k
+    finally:
+        ctx.set_option("spmv_valdict", -1)

@@ -35,18 +35,20 @@ def main():
                       write_factor=n_write * vec_kib / write[(k, "WRITE_SIZE")])
     ff = sum(c["fetch_factor"] for c in cal.values()) / len(cal)
     wf = sum(c["write_factor"] for c in cal.values()) / len(cal)
-    rd = fetch[("spmv_rowblock_kernel", "FETCH_SIZE")] * 1024 * ff
-    wr = write[("spmv_rowblock_kernel", "WRITE_SIZE")] * 1024 * wf
+    # the SpMV kernel of the run: the value-dictionary kernel where the matrix has one, else the CRS-value kernel
+    K = "spmv_rowblock_vd_kernel" if ("spmv_rowblock_vd_kernel", "FETCH_SIZE") in fetch else "spmv_rowblock_kernel"
+    rd = fetch[(K, "FETCH_SIZE")] * 1024 * ff
+    wr = write[(K, "WRITE_SIZE")] * 1024 * wf
     nnz = (3 * size - 2) ** 3
-    out = dict(size=size, kernel="spmv_rowblock_kernel",
-               fetch_size_kib=fetch[("spmv_rowblock_kernel", "FETCH_SIZE")],
-               write_size_kib=write[("spmv_rowblock_kernel", "WRITE_SIZE")],
+    out = dict(size=size, kernel=K,
+               fetch_size_kib=fetch[(K, "FETCH_SIZE")],
+               write_size_kib=write[(K, "WRITE_SIZE")],
                calibration=cal, fetch_correction=ff, write_correction=wf,
                hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr,
                hbm_bytes_per_launch=rd + wr, algorithmic_bytes_per_launch=12 * nnz + 20 * N,
                ratio_to_algorithmic=(rd + wr) / (12 * nnz + 20 * N))
     if tcc:
-        h, m = tcc[("spmv_rowblock_kernel", "TCC_HIT_sum")], tcc[("spmv_rowblock_kernel", "TCC_MISS_sum")]
+        h, m = tcc[(K, "TCC_HIT_sum")], tcc[(K, "TCC_MISS_sum")]
         out["l2_hit_rate"] = h / (h + m)
     print(json.dumps(out, indent=1))
 

@@ -16,7 +16,7 @@ kind, n1 = sys.argv[1], int(sys.argv[2])
 cfgs = [dict(kv.split("=") for kv in c.split(",")) for c in sys.argv[3:]]
 lib = load_library()
 ctx = Context(0)
-A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_anderson(n1)
+A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_fem(n1) if kind == "fem" else ctx.gen_anderson(n1)
 N = A.n_rows
 x, y = ctx.alloc(N), ctx.alloc(N)
 x.set(np.random.default_rng(0).uniform(-1, 1, N))
@@ -24,7 +24,7 @@ b = 12 * A.nnz + 20 * N
 times = [[] for _ in cfgs]
 for rnd in range(int(os.environ.get("ROUNDS", "5"))):
     for i, c in enumerate(cfgs):
-        for k in ("variant", "chunk", "window", "xcd_remap", "packed", "lds_pad"):
+        for k in ("variant", "chunk", "window", "xcd_remap", "packed", "lds_pad", "valdict"):
             lib.bis_set_option(("spmv_" + k).encode(), int(c.get(k if k != "xcd_remap" else "remap", -1)))
         ctx.check(lib.bis_mat_retune(ctx.h, A.h))
         for _ in range(2): ctx.spmv(A, x, y)

@@ -1,0 +1,33 @@
+# Counter passes for the SpMV kernel (one group per run, never combined with trace domains; the program itself follows `--`).
+#   bash tools/spmv_pmc.sh <tag> [valdict]   -> gpurun_out/spmv_pmc_<tag>/
+TAG=$1
+VD=${2:--1}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/spmv_pmc_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+GROUPS_=(
+ "FETCH_SIZE"
+ "WRITE_SIZE"
+ "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+ "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"
+ "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES"
+ "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
+ "SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_FLAT"
+ "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum GRBM_GUI_ACTIVE"
+ "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum"
+ "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
+)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r -- python3 $R/tools/spmv_probe.py hpcg 256 20 $VD > $O/trace.log 2>&1 || echo "trace failed"
+cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
+rm -rf $O/trace
+g=0
+for grp in "${GROUPS_[@]}"; do
+  g=$((g+1))
+  timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/g$g -o r -- python3 $R/tools/spmv_probe.py hpcg 256 20 $VD > $O/g$g.log 2>&1 || echo "pmc group $g failed: $grp"
+  f=$(find $O/g$g -name "*counter_collection.csv")
+  [ -n "$f" ] && python3 $R/tools/pmc_summary_csv.py $f > $O/pmc_g$g.csv
+  rm -rf $O/g$g
+done
+cat $O/pmc_g*.csv | grep -i "spmv\|Kernel" > $O/summary.txt
+ls -la $O
