@@ -76,7 +76,7 @@ struct bis_options {
     int spmv_packed32 = -1; // 1: also try the 32-window packed format (opt-in)
     int spmv_lds_pad = -1; // diagnostic: extra dynamic LDS bytes per workgroup (lowers occupancy)
     int spmv_packed = -1;  // 16-bit packed column stream: 0 off, 1 select tree, 2 lane permute (-1: default = 1)
-    int spmv_valdict = -1; // value dictionary (a matrix with <= 256 distinct values streams 1-byte value codes): 0 off (-1: default = on)
+    int spmv_valdict = -1; // value dictionary (a matrix with <= 256 distinct values streams 1-byte value codes): 0 off, 1 consecutive form only, 2 lane-per-row form where it applies (-1: default)
     int dist_host_plan = -1; // 1: bis_dist_create plans the halo on the host from the downloaded structure (default: on the device)
     int trsv_tiled = -1;    // natural-order sweeps: -1 = tiled sweep (bis_trsv_tiled.hip) where its device plan applies (grid hint), 1 = also with the host plan, 2 = host plan only, 0 = level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
@@ -130,6 +130,12 @@ struct bis_mat {
     double *vdict = nullptr;   // [256], ascending bit patterns, unused entries 0
     int64_t vd_base = 0;
     int vd_state = 0, vd_n = 0;
+    // lane-per-row form of the dictionary kernel: blocks of 256 rows with their own packed column stream
+    int64_t *rm_nnz = nullptr;  // [rm_blocks + 1] row_ptr at every 256th row
+    uint16_t *rm_pk = nullptr;  // column codes against rm_seg's windows, index k - rm_base
+    int32_t *rm_seg = nullptr;  // [rm_blocks * 8]
+    int64_t rm_base = 0;
+    int rm_state = 0, rm_blocks = 0;
     // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
     int32_t *blkf_row = nullptr;
     int64_t *blkf_nnz = nullptr;

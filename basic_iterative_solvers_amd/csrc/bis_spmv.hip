@@ -376,6 +376,114 @@ __global__ __launch_bounds__(256) void spmv_rowblock_vd_kernel(
     }
 }
 
+// Lane-per-row form of the dictionary kernel (y = A x and the fused-dot epilogue): a workgroup takes 256 consecutive
+// rows, copies their column and value codes into LDS with 16- and 8-byte vector loads (3 bytes per non-zero), and
+// lane t then walks row t in CRS order, eight non-zeros at a time: code from LDS, window base by the cross-lane
+// permute, x gathered -- neighbouring lanes are neighbouring rows, so for a stencil the 64 gathers of one instruction
+// fall into consecutive x entries -- value from the table, acc += value * x (two roundings, like the product/sum
+// passes of the other forms: bit-identical y).  No product round trip through LDS, one gather instruction per 64
+// non-zeros as the only vector-memory instruction in the inner loop.
+constexpr int kRmRows = 256;
+constexpr int kRmMaxRow = 40; // LDS: 256 rows * 40 codes * 3 B = 30 KiB
+
+__device__ __forceinline__ int wave_max_i(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <typename RP, int MODE>
+__global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
+    const RP *__restrict__ row_ptr, const double *x, double *y, int64_t n_rows, int n_blocks, int n_blocks_pad8,
+    const double *w, double *partials, const uint16_t *__restrict__ pk, int64_t pk_base, const int32_t *__restrict__ seg_base,
+    const int *stop, const uint8_t *__restrict__ vcode, int64_t vd_base, const double *__restrict__ vdict, int code_cap) {
+    constexpr bool FUSE_DOT = MODE == 1;
+    if (FUSE_DOT && stop && stop[1]) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ double dict[256];
+    const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8)
+                                    : (n_blocks_pad8 < -1 ? xcd_group_remap(blockIdx.x, -n_blocks_pad8) : (int)blockIdx.x);
+    if (b >= n_blocks) return;
+    dict[threadIdx.x] = vdict[threadIdx.x];
+    const int64_t r0 = (int64_t)b * kRmRows;
+    const int rows = (int)min((int64_t)kRmRows, n_rows - r0);
+    const int64_t s = (int64_t)row_ptr[r0], e = (int64_t)row_ptr[r0 + rows];
+    const int64_t s8 = s & ~(int64_t)7;
+    const int first = (int)(s - s8);  // LDS position of the block's first code
+    const int n8 = (int)(e - s8);     // LDS positions [0, n8) get loaded (rounded up to whole vectors of 8)
+    uint16_t *lpk = reinterpret_cast<uint16_t *>(lds_raw);
+    uint8_t *lvc = lds_raw + 2 * (size_t)code_cap;
+    {
+        const uint4 *gpk = reinterpret_cast<const uint4 *>(pk + (s8 - pk_base));
+        const uint2 *gvc = reinterpret_cast<const uint2 *>(vcode + (s8 - vd_base));
+        for (int v = (int)threadIdx.x; v * 8 < n8; v += 256) {
+            reinterpret_cast<uint4 *>(lpk)[v] = gpk[v];
+            reinterpret_cast<uint2 *>(lvc)[v] = gvc[v];
+        }
+    }
+    const bool mine = (int)threadIdx.x < rows;
+    int a = first, len = 0;
+    if (mine) {
+        const int64_t ra = (int64_t)row_ptr[r0 + threadIdx.x];
+        a = (int)(ra - s8);
+        len = (int)((int64_t)row_ptr[r0 + threadIdx.x + 1] - ra);
+    }
+    const int lane_base = seg_base[(size_t)b * 8 + (threadIdx.x & 7)];
+    const char *xb = reinterpret_cast<const char *>(x);
+    __syncthreads();
+    double acc = 0.0;
+    const int wmax = __builtin_amdgcn_readfirstlane(wave_max_i(len)), wmin = __builtin_amdgcn_readfirstlane(wave_min_i(len)); // wave-uniform
+    for (int j0 = 0; j0 < wmax; j0 += 8) {
+        double xx[8], vv[8];
+        if (j0 + 8 <= wmin) { // every row of the wave has these eight entries
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = a + j0 + q;
+                const unsigned code = lpk[idx];
+                const int wbase = __builtin_amdgcn_ds_bpermute((int)((code >> (kPkOffBits - 2)) & 28u), lane_base);
+                xx[q] = x_at<false>(xb, wbase + (int)(code & (kPkSpan - 1)));
+                vv[q] = dict[lvc[idx]];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double pr = vv[q] * xx[q];
+                asm volatile("" : "+v"(pr));
+                acc += pr;
+            }
+        } else { // ragged tail: lanes past their row's end re-read the block's first code and drop the product
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = j0 + q < len ? a + j0 + q : first;
+                const unsigned code = lpk[idx];
+                const int wbase = __builtin_amdgcn_ds_bpermute((int)((code >> (kPkOffBits - 2)) & 28u), lane_base);
+                xx[q] = x_at<false>(xb, wbase + (int)(code & (kPkSpan - 1)));
+                vv[q] = dict[lvc[idx]];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double pr = vv[q] * xx[q];
+                asm volatile("" : "+v"(pr));
+                if (j0 + q < len) acc += pr;
+            }
+        }
+    }
+    if (mine) y[r0 + threadIdx.x] = acc;
+    if (FUSE_DOT) {
+        const double t = wave_sum(mine ? acc * w[r0 + threadIdx.x] : 0.0);
+        if ((threadIdx.x & 63) == 0) partials[(size_t)b * 4 + (threadIdx.x >> 6)] = t;
+    }
+}
+
+// rm_nnz[k] = row_ptr[min(256 k, n_rows)]
+template <typename RP>
+__global__ __launch_bounds__(256) void rm_blocks_kernel(const RP *__restrict__ row_ptr, int64_t n_rows, int n_blocks, int64_t *__restrict__ rm_nnz) {
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (k <= n_blocks) rm_nnz[k] = (int64_t)row_ptr[min((int64_t)k * kRmRows, n_rows)];
+}
+
 // distinct values of val[s, e), one list per wave (a workgroup is one wave): lists[w * 257] = count (257 = more than
 // 256, *overflow is raised and every wave stops), then the values' bit patterns
 __global__ __launch_bounds__(64) void vd_collect_kernel(const double *__restrict__ val, int64_t s, int64_t e,
@@ -776,9 +884,52 @@ void bis_spmv_drop_packed(bis_mat *A) {
 void bis_spmv_drop_valdict(bis_mat *A) {
     hipFree(A->vcode); hipFree(A->vdict);
     A->vcode = nullptr; A->vdict = nullptr; A->vd_state = 0; A->vd_n = 0;
+    hipFree(A->rm_nnz); hipFree(A->rm_pk); hipFree(A->rm_seg);
+    A->rm_nnz = nullptr; A->rm_pk = nullptr; A->rm_seg = nullptr; A->rm_state = 0; A->rm_blocks = 0;
 }
 
-static int spmv_valdict_mode() { return bis_opts().spmv_valdict < 0 ? 1 : bis_opts().spmv_valdict; }
+// the 256-row blocks of the lane-per-row form and their packed column stream; rm_state tells the outcome
+static bis_status spmv_try_rowmajor(bis_ctx *ctx, bis_mat *A) {
+    if (A->rm_state != 0) return BIS_OK;
+    A->rm_state = -1;
+    if (A->vd_state != 1 || A->view || A->n_rows == 0 || A->max_row_nnz > kRmMaxRow || A->n_cols >= ((int64_t)1 << 29)) return BIS_OK;
+    const int64_t nb64 = (A->n_rows + kRmRows - 1) / kRmRows;
+    if (nb64 > (int64_t)1 << 28) return BIS_OK;
+    const int nb = (int)nb64;
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->rm_nnz, sizeof(int64_t) * (size_t)(nb + 1)));
+    if (A->rp64) hipLaunchKernelGGL(rm_blocks_kernel<int64_t>, dim3((unsigned)(nb / 256 + 1)), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->n_rows, nb, A->rm_nnz);
+    else hipLaunchKernelGGL(rm_blocks_kernel<int32_t>, dim3((unsigned)(nb / 256 + 1)), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->n_rows, nb, A->rm_nnz);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    int64_t ends[2];
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[0], A->rm_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[1], A->rm_nnz + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    A->rm_base = ends[0] & ~(int64_t)7;
+    if (A->rm_base < A->vd_base) return BIS_OK; // (both are the first row's start rounded down: cannot happen)
+    const size_t n_pk = (size_t)(ends[1] - A->rm_base) + 16;
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->rm_pk, sizeof(uint16_t) * n_pk));
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->rm_seg, sizeof(int32_t) * (size_t)nb * 8));
+    int *status = (int *)ctx->counters + 47;
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(A->rm_pk, 0, sizeof(uint16_t) * n_pk, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL((pk_build_kernel<kPkSegs, kPkOffBits>), dim3(nb), dim3(256), 0, ctx->stream, A->col, A->rm_nnz, nb, A->rm_base,
+                       A->rm_pk, A->rm_seg, status);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    int h = 0;
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h) { // some block of 256 rows needs a ninth column window: the consecutive form stays
+        hipFree(A->rm_nnz); hipFree(A->rm_pk); hipFree(A->rm_seg);
+        A->rm_nnz = nullptr; A->rm_pk = nullptr; A->rm_seg = nullptr;
+        return BIS_OK;
+    }
+    A->rm_blocks = nb;
+    A->rm_state = 1;
+    return BIS_OK;
+}
+
+// 0 off, 1 consecutive form, 2 lane-per-row form for y = A x and the fused dot where the matrix qualifies
+static int spmv_valdict_mode() { return bis_opts().spmv_valdict < 0 ? 2 : bis_opts().spmv_valdict; }
 
 bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
     if (A->vd_state != 0) return BIS_OK;
@@ -818,7 +969,7 @@ bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
     if (all.empty() || all.size() > 256) return BIS_OK;
     unsigned long long table[256] = {};
     std::copy(all.begin(), all.end(), table);
-    A->vd_base = s & ~(int64_t)3;
+    A->vd_base = s & ~(int64_t)7; // whole 8-byte vectors of codes for the lane-per-row form
     const size_t n_code = (size_t)(e - A->vd_base) + 16;
     BIS_HIP_CHECK(ctx, hipMalloc(&A->vdict, sizeof table));
     he = hipMalloc(&A->vcode, n_code);
@@ -961,6 +1112,33 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     a.grid = grid_for_map(nb, a.remap_arg);
     if (bis_status st = ensure_packed(ctx, A, use_f ? 1 : 0, &a)) return st;
     a.stop = w ? ctx->spmv_stop : nullptr;
+    if (a.vcode && spmv_valdict_mode() >= 2 && spmv_variant(a) == 20 && a.pk_mode == 1) { // lane-per-row form
+        bis_mat *Am = const_cast<bis_mat *>(A);
+        if (bis_status st = spmv_try_rowmajor(ctx, Am)) return st;
+        if (A->rm_state == 1) {
+            const int nbr = A->rm_blocks, nbr8 = (nbr + 7) & ~7;
+            if (w && partials_off + (size_t)nbr * 4 > ctx->partials_cap) {
+                ctx->err = "bis_spmv: partials buffer too small (internal)";
+                return BIS_ERR_INVALID;
+            }
+            const int remap_arg = remap_arg_for(nbr8);
+            const int grid = grid_for_map(nbr, remap_arg);
+            const int code_cap = kRmRows * std::max(A->max_row_nnz, 1) + 16; // positions: a block's codes + the 8-alignment slack on both sides
+            const size_t lds = 3 * (size_t)code_cap;
+            bis_prof_begin(ctx);
+#define BIS_RM_LAUNCH(RP, MODE)                                                                                        \
+    hipLaunchKernelGGL((spmv_rowmajor_vd_kernel<RP, MODE>), dim3(grid), dim3(256), lds, ctx->stream, (const RP *)A->row_ptr, x, y, \
+                       A->n_rows, nbr, remap_arg, w, ctx->partials + partials_off, A->rm_pk, A->rm_base, A->rm_seg, a.stop,       \
+                       A->vcode, A->vd_base, A->vdict, code_cap)
+            if (A->rp64) { if (w) BIS_RM_LAUNCH(int64_t, 1); else BIS_RM_LAUNCH(int64_t, 0); }
+            else { if (w) BIS_RM_LAUNCH(int32_t, 1); else BIS_RM_LAUNCH(int32_t, 0); }
+#undef BIS_RM_LAUNCH
+            bis_prof_end(ctx);
+            BIS_HIP_CHECK(ctx, hipGetLastError());
+            if (w && n_partials) *n_partials = nbr * 4;
+            return BIS_OK;
+        }
+    }
     if (bis_opts().spmv_lds_pad > 0) a.lds_bytes += (size_t)bis_opts().spmv_lds_pad;
     bis_prof_begin(ctx);
     const bool ok = A->rp64 ? launch_by_id<int64_t>(spmv_variant(a), a)

@@ -343,7 +343,8 @@ def main():
         leg = crs_value_leg(ctx, A, b, x, D, min(args.steps, 50), min(args.warmup, 5))
         h2 = np.array(leg.pop("residual_history"))
         m2 = min(len(h2), len(hist))
-        leg["history_bit_identical_to_timed_run"] = bool(np.array_equal(h2[:m2], np.array(hist[:m2])))
+        # same y bit for bit; the fused (Ap, p) is summed over different row blocks, a different fixed order
+        leg["history_max_dev_over_r0_vs_timed_run"] = float(np.max(np.abs(h2[:m2] - np.array(hist[:m2]))) / h2[0])
         out["crs_value_stream"] = leg
     A.free(); b.free(); x.free()
     if n1 == 256 and not args.no_target_512:
