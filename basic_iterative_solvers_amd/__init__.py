@@ -350,10 +350,10 @@ class Mat:
         return int(self.ctx.lib.bis_mat_rp_width(self.h))
 
     def spmv_stream_info(self):
-        """(col_bytes, val_bytes, n_dict) the SpMV streams per non-zero (bis_mat_spmv_stream_info)."""
-        c, v, d = C.c_int(), C.c_int(), C.c_int()
-        self.ctx.check(self.ctx.lib.bis_mat_spmv_stream_info(self.ctx.h, self.h, C.byref(c), C.byref(v), C.byref(d)))
-        return c.value, v.value, d.value
+        """(col_bytes, val_bytes, n_dict, form) of the SpMV's streams for this matrix (bis_mat_spmv_stream_info)."""
+        c, v, d, f = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.bis_mat_spmv_stream_info(self.ctx.h, self.h, C.byref(c), C.byref(v), C.byref(d), C.byref(f)))
+        return c.value, v.value, d.value, f.value
 
     def set_grid_hint(self, nx, ny, nz, dof=1):
         self.ctx.check(self.ctx.lib.bis_mat_set_grid_hint(self.h, _i64(nx), _i64(ny), _i64(nz), C.c_int(dof)))

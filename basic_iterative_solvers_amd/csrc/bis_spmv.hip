@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void spmv_rowblock_vd_kernel(
     }
 }
 
-// Lane-per-row form of the dictionary kernel (y = A x and the fused-dot epilogue): a workgroup takes 256 consecutive
+// Lane-per-row form of the dictionary kernel (same three epilogues): a workgroup takes 256 consecutive
 // rows, copies their column and value codes into LDS with 16- and 8-byte vector loads (3 bytes per non-zero), and
 // lane t then walks row t in CRS order, eight non-zeros at a time: code from LDS, window base by the cross-lane
 // permute, x gathered -- neighbouring lanes are neighbouring rows, so for a stencil the 64 gathers of one instruction
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
             }
         }
     }
-    if (mine) y[r0 + threadIdx.x] = acc;
+    if (mine) y[r0 + threadIdx.x] = MODE == 2 ? (w[r0 + threadIdx.x] - acc) / partials[r0 + threadIdx.x] : acc; // MODE 2: one triangular-sweep level
     if (FUSE_DOT) {
         const double t = wave_sum(mine ? acc * w[r0 + threadIdx.x] : 0.0);
         if ((threadIdx.x & 63) == 0) partials[(size_t)b * 4 + (threadIdx.x >> 6)] = t;
@@ -892,7 +892,7 @@ void bis_spmv_drop_valdict(bis_mat *A) {
 static bis_status spmv_try_rowmajor(bis_ctx *ctx, bis_mat *A) {
     if (A->rm_state != 0) return BIS_OK;
     A->rm_state = -1;
-    if (A->vd_state != 1 || A->view || A->n_rows == 0 || A->max_row_nnz > kRmMaxRow || A->n_cols >= ((int64_t)1 << 29)) return BIS_OK;
+    if (A->vd_state != 1 || A->n_rows == 0 || A->max_row_nnz > kRmMaxRow || A->n_cols >= ((int64_t)1 << 29)) return BIS_OK;
     const int64_t nb64 = (A->n_rows + kRmRows - 1) / kRmRows;
     if (nb64 > (int64_t)1 << 28) return BIS_OK;
     const int nb = (int)nb64;
@@ -1057,6 +1057,37 @@ static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArg
     return BIS_OK;
 }
 
+// lane-per-row form of the dictionary kernel where the matrix qualifies (*done tells); mode 0 / 1 / 2 as in SpmvArgs
+static bis_status launch_rowmajor(bis_ctx *ctx, const bis_mat *A, const SpmvArgs &a, const double *x, double *y, int mode,
+                                  const double *w, double *partials, size_t partials_off, int *n_partials, bool *done) {
+    *done = false;
+    if (!(a.vcode && spmv_valdict_mode() >= 2 && spmv_variant(a) == 20 && a.pk_mode == 1)) return BIS_OK;
+    if (bis_status st = spmv_try_rowmajor(ctx, const_cast<bis_mat *>(A))) return st;
+    if (A->rm_state != 1) return BIS_OK;
+    const int nbr = A->rm_blocks, nbr8 = (nbr + 7) & ~7;
+    if (mode == 1 && partials_off + (size_t)nbr * 4 > ctx->partials_cap) {
+        ctx->err = "bis_spmv: partials buffer too small (internal)";
+        return BIS_ERR_INVALID;
+    }
+    const int remap_arg = remap_arg_for(nbr8);
+    const int grid = grid_for_map(nbr, remap_arg);
+    const int code_cap = kRmRows * std::max(A->max_row_nnz, 1) + 16; // positions: a block's codes + the 8-alignment slack on both sides
+    const size_t lds = 3 * (size_t)code_cap;
+    double *pp = mode == 1 ? partials + partials_off : partials;
+    if (mode != 2) bis_prof_begin(ctx);
+#define BIS_RM_LAUNCH(RP, MODE)                                                                                        \
+    hipLaunchKernelGGL((spmv_rowmajor_vd_kernel<RP, MODE>), dim3(grid), dim3(256), lds, ctx->stream, (const RP *)A->row_ptr, x, y, \
+                       A->n_rows, nbr, remap_arg, w, pp, A->rm_pk, A->rm_base, A->rm_seg, a.stop, A->vcode, A->vd_base, A->vdict, code_cap)
+    if (A->rp64) { if (mode == 2) BIS_RM_LAUNCH(int64_t, 2); else if (mode == 1) BIS_RM_LAUNCH(int64_t, 1); else BIS_RM_LAUNCH(int64_t, 0); }
+    else { if (mode == 2) BIS_RM_LAUNCH(int32_t, 2); else if (mode == 1) BIS_RM_LAUNCH(int32_t, 1); else BIS_RM_LAUNCH(int32_t, 0); }
+#undef BIS_RM_LAUNCH
+    if (mode != 2) bis_prof_end(ctx);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    if (mode == 1 && n_partials) *n_partials = nbr * 4;
+    *done = true;
+    return BIS_OK;
+}
+
 // internal: y = A x, optionally partials[b] = sum_{r in block b} y[r]*w[r]
 // (n_partials returns the number of partials written; 0 if not fused).
 bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y,
@@ -1112,32 +1143,10 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     a.grid = grid_for_map(nb, a.remap_arg);
     if (bis_status st = ensure_packed(ctx, A, use_f ? 1 : 0, &a)) return st;
     a.stop = w ? ctx->spmv_stop : nullptr;
-    if (a.vcode && spmv_valdict_mode() >= 2 && spmv_variant(a) == 20 && a.pk_mode == 1) { // lane-per-row form
-        bis_mat *Am = const_cast<bis_mat *>(A);
-        if (bis_status st = spmv_try_rowmajor(ctx, Am)) return st;
-        if (A->rm_state == 1) {
-            const int nbr = A->rm_blocks, nbr8 = (nbr + 7) & ~7;
-            if (w && partials_off + (size_t)nbr * 4 > ctx->partials_cap) {
-                ctx->err = "bis_spmv: partials buffer too small (internal)";
-                return BIS_ERR_INVALID;
-            }
-            const int remap_arg = remap_arg_for(nbr8);
-            const int grid = grid_for_map(nbr, remap_arg);
-            const int code_cap = kRmRows * std::max(A->max_row_nnz, 1) + 16; // positions: a block's codes + the 8-alignment slack on both sides
-            const size_t lds = 3 * (size_t)code_cap;
-            bis_prof_begin(ctx);
-#define BIS_RM_LAUNCH(RP, MODE)                                                                                        \
-    hipLaunchKernelGGL((spmv_rowmajor_vd_kernel<RP, MODE>), dim3(grid), dim3(256), lds, ctx->stream, (const RP *)A->row_ptr, x, y, \
-                       A->n_rows, nbr, remap_arg, w, ctx->partials + partials_off, A->rm_pk, A->rm_base, A->rm_seg, a.stop,       \
-                       A->vcode, A->vd_base, A->vdict, code_cap)
-            if (A->rp64) { if (w) BIS_RM_LAUNCH(int64_t, 1); else BIS_RM_LAUNCH(int64_t, 0); }
-            else { if (w) BIS_RM_LAUNCH(int32_t, 1); else BIS_RM_LAUNCH(int32_t, 0); }
-#undef BIS_RM_LAUNCH
-            bis_prof_end(ctx);
-            BIS_HIP_CHECK(ctx, hipGetLastError());
-            if (w && n_partials) *n_partials = nbr * 4;
-            return BIS_OK;
-        }
+    {
+        bool done = false;
+        if (bis_status st = launch_rowmajor(ctx, A, a, x, y, w ? 1 : 0, w, ctx->partials, partials_off, n_partials, &done)) return st;
+        if (done) return BIS_OK;
     }
     if (bis_opts().spmv_lds_pad > 0) a.lds_bytes += (size_t)bis_opts().spmv_lds_pad;
     bis_prof_begin(ctx);
@@ -1166,6 +1175,11 @@ bis_status bis_spmv_trsv_level(bis_ctx *ctx, const bis_mat *T, const double *x, 
     a.remap_arg = remap_arg_for(nb8);
     a.grid = grid_for_map(nb, a.remap_arg);
     if (bis_status st = ensure_packed(ctx, T, 0, &a)) return st;
+    {
+        bool done = false;
+        if (bis_status st = launch_rowmajor(ctx, T, a, x, y, 2, b, const_cast<double *>(D), 0, nullptr, &done)) return st;
+        if (done) return BIS_OK;
+    }
     const bool ok = T->rp64 ? launch_by_id<int64_t>(spmv_variant(a), a) : launch_by_id<int32_t>(spmv_variant(a), a);
     if (!ok) return BIS_ERR_INVALID;
     BIS_HIP_CHECK(ctx, hipGetLastError());
@@ -1181,7 +1195,7 @@ bis_status bis_spmv(bis_ctx *ctx, const bis_mat *A, const double *x, double *y) 
     return bis_spmv_launch(ctx, A, x, y, nullptr, nullptr);
 }
 
-bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_bytes, int *val_bytes, int *n_dict) {
+bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_bytes, int *val_bytes, int *n_dict, int *form) {
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, A, "bis_mat_spmv_stream_info: bad arguments");
     SpmvArgs a{};
@@ -1192,6 +1206,12 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
     if (col_bytes) *col_bytes = a.pk_mode ? 2 : 4;
     if (val_bytes) *val_bytes = vd ? 1 : 8;
     if (n_dict) *n_dict = vd ? A->vd_n : 0;
+    int f = vd ? 1 : 0;
+    if (vd && spmv_valdict_mode() >= 2) {
+        if (bis_status st = spmv_try_rowmajor(ctx, const_cast<bis_mat *>(A))) return st;
+        if (A->rm_state == 1) f = 2;
+    }
+    if (form) *form = f;
     return BIS_OK;
 }
 

@@ -102,9 +102,9 @@ def measured_stream(ctx, N):
 
 def stream_format(A):
     """What the SpMV streams per non-zero for this matrix (bis_mat_spmv_stream_info)."""
-    col_b, val_b, n_dict = A.spmv_stream_info()
+    col_b, val_b, n_dict, form = A.spmv_stream_info()
     return {"col_bytes": col_b, "val_bytes": val_b, "dictionary_values": n_dict,
-            "kernel": "spmv_rowblock_vd_kernel" if val_b == 1 else "spmv_rowblock_kernel",
+            "kernel": ("spmv_rowblock_kernel", "spmv_rowblock_vd_kernel", "spmv_rowmajor_vd_kernel")[form],
             "streamed_bytes_per_nnz": col_b + val_b}
 
 

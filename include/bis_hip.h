@@ -132,13 +132,16 @@ BIS_API int bis_mat_rp_width(const bis_mat *A);
  * 2 (packed 16-bit column codes); val_bytes 8 (CRS values) or 1 (value
  * dictionary: the matrix has n_dict <= 256 distinct values, compared bit for
  * bit -- every constant-coefficient stencil -- which the kernel keeps in LDS and
- * indexes with a 1-byte code per non-zero; n_dict = 0 without a dictionary).
- * Both are lossless re-encodings of the CRS arrays, which stay authoritative:
+ * indexes with a 1-byte code per non-zero; n_dict = 0 without a dictionary);
+ * form 0 = the CRS-value kernel, 1 = dictionary kernel, consecutive non-zeros
+ * per lane, 2 = dictionary kernel, a lane per row with the codes staged through
+ * LDS (rows of at most 40 entries, at most 8 column windows per 256 rows).
+ * All are lossless re-encodings of the CRS arrays, which stay authoritative:
  * same products, same summation order, bit-identical y.  Option
- * "spmv_valdict" 0 switches the dictionary off. */
+ * "spmv_valdict" 0 switches the dictionary off, 1 allows form 1 only. */
 BIS_API bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A,
                                             int *col_bytes, int *val_bytes,
-                                            int *n_dict);
+                                            int *n_dict, int *form);
 /* Structured-grid hint: the rows are the unknowns of an nx x ny x nz grid, x
  * fastest, dof unknowns per node (row = ((z*ny + y)*nx + x)*dof + d) -- e.g.
  * an HPCG-n.mtx read from a file.  The generators set it themselves; strict

@@ -974,11 +974,12 @@ def test_spmv_value_dictionary(ctx, oracle, form, rp64):
             for mode in (0, form):
                 ctx.set_option("spmv_valdict", mode)
                 dA = ctx.matrix(A)
-                col_b, val_b, n_dict = dA.spmv_stream_info()
+                col_b, val_b, n_dict, kform = dA.spmv_stream_info()
                 if mode == 0:
-                    assert (val_b, n_dict) == (8, 0)
+                    assert (val_b, n_dict, kform) == (8, 0, 0)
                 elif want_dict is not None and col_b == 2:
                     assert (val_b, n_dict) == ((1, want_dict) if want_dict else (8, 0)), name
+                    assert kform == (form if want_dict else 0), name  # every dictionary case here has short rows and few windows
                 dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
                 ctx.spmv(dA, dx, dy)
                 ys[mode] = dy.to_host()
@@ -995,7 +996,7 @@ def test_spmv_value_dictionary(ctx, oracle, form, rp64):
         x = rng.uniform(-1, 1, A.n_rows)
         dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
         ctx.spmv(dA, dx, dy)
-        assert dA.spmv_stream_info()[1:] == (1, 2)
+        assert dA.spmv_stream_info()[1:3] == (1, 2)
         s = ctx.scale_sym(dA)
         ctx.spmv(dA, dx, dy)
         sv = s.to_host()
@@ -1034,7 +1035,7 @@ def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form):
             ctx.bsptrsv(Us, xb, D, rhs)
             out[mode] = (np.array(hist), x.to_host(), xf.to_host(), xb.to_host(), dA.spmv_stream_info())
             cg.free()
-        assert out[0][4][1:] == (8, 0) and out[form][4][1:] == (1, 2)
+        assert out[0][4][1:] == (8, 0, 0) and out[form][4][1:] == (1, 2, form)
         for k in range(4):
             if form == 2 and k < 2:
                 tol = 1e-12 * out[0][0][0] if k == 0 else 1e-10 * np.max(np.abs(out[0][1]))

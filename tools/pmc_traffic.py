@@ -36,7 +36,7 @@ def main():
     ff = sum(c["fetch_factor"] for c in cal.values()) / len(cal)
     wf = sum(c["write_factor"] for c in cal.values()) / len(cal)
     # the SpMV kernel of the run: the value-dictionary kernel where the matrix has one, else the CRS-value kernel
-    K = "spmv_rowblock_vd_kernel" if ("spmv_rowblock_vd_kernel", "FETCH_SIZE") in fetch else "spmv_rowblock_kernel"
+    K = next(k for k in ("spmv_rowmajor_vd_kernel", "spmv_rowblock_vd_kernel", "spmv_rowblock_kernel") if (k, "FETCH_SIZE") in fetch)
     rd = fetch[(K, "FETCH_SIZE")] * 1024 * ff
     wr = write[(K, "WRITE_SIZE")] * 1024 * wf
     nnz = (3 * size - 2) ** 3

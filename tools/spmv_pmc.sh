@@ -29,5 +29,5 @@ for grp in "${GROUPS_[@]}"; do
   [ -n "$f" ] && python3 $R/tools/pmc_summary_csv.py $f > $O/pmc_g$g.csv
   rm -rf $O/g$g
 done
-cat $O/pmc_g*.csv | grep -i "spmv\|Kernel" > $O/summary.txt
+cat $O/pmc_g*.csv | grep -i "spmv_row\|Kernel" > $O/summary.txt
 ls -la $O
