@@ -130,6 +130,11 @@ struct bis_mat {
     double *vdict = nullptr;   // [256], ascending bit patterns, unused entries 0
     int64_t vd_base = 0;
     int vd_state = 0, vd_n = 0;
+    // ... or all values EXCEPT the diagonal entries (col == row + view_row0) are at most 255: code 255 then stands for "this
+    // row's diagonal value", kept in a per-row array (Anderson: random diagonal, constant hopping).  Lane-per-row form only.
+    double *vdiag = nullptr;   // [n_rows] when vd_diag
+    bool vd_diag = false;
+    int64_t view_row0 = 0;     // row views: first row of the view in the matrix it was cut from
     // lane-per-row form of the dictionary kernel: blocks of 256 rows with their own packed column stream
     int64_t *rm_nnz = nullptr;  // [rm_blocks + 1] row_ptr at every 256th row
     uint16_t *rm_pk = nullptr;  // column codes against rm_seg's windows, index k - rm_base

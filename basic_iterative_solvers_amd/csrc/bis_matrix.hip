@@ -454,6 +454,7 @@ bis_status bis_mat_row_view(bis_ctx *ctx, const bis_mat *A, int64_t ra, int64_t 
     V->rp64 = A->rp64;
     V->n_rows = rb - ra;
     V->n_cols = A->n_cols;
+    V->view_row0 = A->view_row0 + ra;
     V->nnz = ends[1] - ends[0];
     V->row_ptr = (char *)A->row_ptr + w * ra;
     V->col = A->col;

@@ -395,11 +395,14 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return v;
 }
 
-template <typename RP, int MODE>
+// DIAG: value code 255 stands for the row's own diagonal value vdiag[row] (matrices whose off-diagonal values are few
+// but whose diagonal is not: Anderson's random potential).
+template <typename RP, int MODE, bool DIAG>
 __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
     const RP *__restrict__ row_ptr, const double *x, double *y, int64_t n_rows, int n_blocks, int n_blocks_pad8,
     const double *w, double *partials, const uint16_t *__restrict__ pk, int64_t pk_base, const int32_t *__restrict__ seg_base,
-    const int *stop, const uint8_t *__restrict__ vcode, int64_t vd_base, const double *__restrict__ vdict, int code_cap) {
+    const int *stop, const uint8_t *__restrict__ vcode, int64_t vd_base, const double *__restrict__ vdict, int code_cap,
+    const double *__restrict__ vdiag) {
     constexpr bool FUSE_DOT = MODE == 1;
     if (FUSE_DOT && stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -426,10 +429,12 @@ __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
     }
     const bool mine = (int)threadIdx.x < rows;
     int a = first, len = 0;
+    double dval = 0.0;
     if (mine) {
         const int64_t ra = (int64_t)row_ptr[r0 + threadIdx.x];
         a = (int)(ra - s8);
         len = (int)((int64_t)row_ptr[r0 + threadIdx.x + 1] - ra);
+        if (DIAG) dval = vdiag[r0 + threadIdx.x];
     }
     const int lane_base = seg_base[(size_t)b * 8 + (threadIdx.x & 7)];
     const char *xb = reinterpret_cast<const char *>(x);
@@ -445,7 +450,9 @@ __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
                 const unsigned code = lpk[idx];
                 const int wbase = __builtin_amdgcn_ds_bpermute((int)((code >> (kPkOffBits - 2)) & 28u), lane_base);
                 xx[q] = x_at<false>(xb, wbase + (int)(code & (kPkSpan - 1)));
-                vv[q] = dict[lvc[idx]];
+                const unsigned vcd = lvc[idx];
+                vv[q] = dict[vcd];
+                if (DIAG) vv[q] = vcd == 255u ? dval : vv[q];
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -460,7 +467,9 @@ __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
                 const unsigned code = lpk[idx];
                 const int wbase = __builtin_amdgcn_ds_bpermute((int)((code >> (kPkOffBits - 2)) & 28u), lane_base);
                 xx[q] = x_at<false>(xb, wbase + (int)(code & (kPkSpan - 1)));
-                vv[q] = dict[lvc[idx]];
+                const unsigned vcd = lvc[idx];
+                vv[q] = dict[vcd];
+                if (DIAG) vv[q] = vcd == 255u ? dval : vv[q];
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -510,6 +519,73 @@ __global__ __launch_bounds__(64) void vd_collect_kernel(const double *__restrict
     if (n > 256 && lane == 0) atomicExch(overflow, 1);
     if (lane == 0) lists[(size_t)blockIdx.x * 257] = (unsigned long long)n;
     for (int j = lane; j < n && j < 256; j += 64) lists[(size_t)blockIdx.x * 257 + 1 + j] = list[j];
+}
+
+// Row-wise variants for the "dictionary + per-row diagonal" encoding: a lane per row, diagonal entries (col == row +
+// row0) are left out of the dictionary.  *overflow: 1 = more than 255 distinct off-diagonal values, 2 = a row with more
+// than one diagonal entry (its values could differ: not representable).
+template <typename RP>
+__global__ __launch_bounds__(64) void vd_collect_rows_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                             const double *__restrict__ val, int64_t n_rows, int64_t row0,
+                                                             unsigned long long *__restrict__ lists, int *overflow) {
+    __shared__ unsigned long long list[256];
+    const int lane = threadIdx.x;
+    int n = 0;
+    for (int64_t rb = (int64_t)blockIdx.x * 64; rb < n_rows && n <= 255; rb += (int64_t)gridDim.x * 64) {
+        if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { n = 256; break; }
+        const int64_t r = rb + lane;
+        int64_t k = 0, k1 = 0;
+        if (r < n_rows) { k = (int64_t)row_ptr[r]; k1 = (int64_t)row_ptr[r + 1]; }
+        int n_diag = 0;
+        while (__ballot(k < k1) && n <= 255) {
+            bool found = true;
+            unsigned long long v = 0;
+            if (k < k1) {
+                if ((int64_t)col[k] == r + row0) ++n_diag;
+                else { v = (unsigned long long)__double_as_longlong(val[k]); found = false; }
+                ++k;
+            }
+            for (int j = 0; j < n && __ballot(!found); ++j) found |= list[j] == v;
+            while (const unsigned long long open = __ballot(!found)) {
+                const int leader = (int)__builtin_ctzll(open);
+                const unsigned long long lv = __shfl(v, leader);
+                if (n == 255) { n = 256; break; }
+                if (lane == 0) list[n] = lv;
+                ++n;
+                found |= v == lv;
+            }
+            __syncthreads();
+        }
+        if (__ballot(n_diag > 1)) { if (lane == 0) atomicExch(overflow, 2); n = 256; }
+    }
+    if (n > 255 && lane == 0) atomicCAS(overflow, 0, 1);
+    if (lane == 0) lists[(size_t)blockIdx.x * 257] = (unsigned long long)n;
+    for (int j = lane; j < n && j < 255; j += 64) lists[(size_t)blockIdx.x * 257 + 1 + j] = list[j];
+}
+
+template <typename RP>
+__global__ __launch_bounds__(256) void vd_encode_rows_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                             const double *__restrict__ val, int64_t n_rows, int64_t row0, int64_t base,
+                                                             const double *__restrict__ vdict, int n_dict, uint8_t *__restrict__ vcode,
+                                                             double *__restrict__ vdiag) {
+    __shared__ unsigned long long dict[256];
+    dict[threadIdx.x] = (unsigned long long)__double_as_longlong(vdict[threadIdx.x]);
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += stride) {
+        double d = 0.0;
+        for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) {
+            if ((int64_t)col[k] == r + row0) { d = val[k]; vcode[k - base] = 255; continue; }
+            const unsigned long long v = (unsigned long long)__double_as_longlong(val[k]);
+            int lo = 0, hi = n_dict - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (dict[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            vcode[k - base] = (uint8_t)lo;
+        }
+        vdiag[r] = d;
+    }
 }
 
 // vcode[k - base] = index of val[k] in the (ascending) dictionary; four codes per thread, one 32-bit store
@@ -748,6 +824,7 @@ struct SpmvArgs {
     bool wide = false; // 2^29 columns or more: 64-bit x addressing, 32-bit column stream
     const int *stop = nullptr;
     const uint8_t *vcode = nullptr; int64_t vd_base = 0; const double *vdict = nullptr; // value dictionary (pk_mode 1 only)
+    bool vd_diag = false; // code 255 = the row's diagonal value: lane-per-row kernel only
 };
 
 template <typename RP, int T, int U, int BR = 0>
@@ -782,7 +859,7 @@ void launch_vd(const SpmvArgs &a) {
 
 template <typename RP>
 bool launch_by_id(int id, const SpmvArgs &a) {
-    if (a.vcode && id == 20 && a.pk_mode == 1) { // value dictionary: the default form only
+    if (a.vcode && !a.vd_diag && id == 20 && a.pk_mode == 1) { // value dictionary: the default form only
         if (a.mode == 2) launch_vd<RP, 2>(a);
         else if (a.mode == 1) launch_vd<RP, 1>(a);
         else launch_vd<RP, 0>(a);
@@ -882,8 +959,8 @@ void bis_spmv_drop_packed(bis_mat *A) {
 }
 
 void bis_spmv_drop_valdict(bis_mat *A) {
-    hipFree(A->vcode); hipFree(A->vdict);
-    A->vcode = nullptr; A->vdict = nullptr; A->vd_state = 0; A->vd_n = 0;
+    hipFree(A->vcode); hipFree(A->vdict); hipFree(A->vdiag);
+    A->vcode = nullptr; A->vdict = nullptr; A->vdiag = nullptr; A->vd_diag = false; A->vd_state = 0; A->vd_n = 0;
     hipFree(A->rm_nnz); hipFree(A->rm_pk); hipFree(A->rm_seg);
     A->rm_nnz = nullptr; A->rm_pk = nullptr; A->rm_seg = nullptr; A->rm_state = 0; A->rm_blocks = 0;
 }
@@ -931,23 +1008,22 @@ static bis_status spmv_try_rowmajor(bis_ctx *ctx, bis_mat *A) {
 // 0 off, 1 consecutive form, 2 lane-per-row form for y = A x and the fused dot where the matrix qualifies
 static int spmv_valdict_mode() { return bis_opts().spmv_valdict < 0 ? 2 : bis_opts().spmv_valdict; }
 
-bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
-    if (A->vd_state != 0) return BIS_OK;
-    A->vd_state = -1;
-    if (A->nnz == 0 || A->n_blocks == 0) return BIS_OK;
-    int64_t ends[2];
-    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[0], A->blk_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
-    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[1], A->blk_nnz + A->n_blocks, 8, hipMemcpyDeviceToHost, ctx->stream));
-    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t s = ends[0], e = ends[1];
-    if (e <= s) return BIS_OK;
-    const int n_waves = (int)std::min<int64_t>((e - s + 63) / 64, (int64_t)ctx->n_cus * 8);
+// distinct values of the matrix (plain), or of its off-diagonal entries (diag): at most `cap` bit patterns, ascending;
+// *ok = false when there are more (or, diag, when a row has several diagonal entries)
+static bis_status vd_collect(bis_ctx *ctx, const bis_mat *A, int64_t s, int64_t e, bool diag, std::vector<unsigned long long> *all, bool *ok) {
+    *ok = false;
+    all->clear();
+    const size_t cap = diag ? 255 : 256;
+    const int64_t units = diag ? A->n_rows : e - s;
+    const int n_waves = (int)std::min<int64_t>((units + 63) / 64, (int64_t)ctx->n_cus * 8);
     unsigned long long *lists = nullptr;
     int *overflow = (int *)ctx->counters + 46;
     BIS_HIP_CHECK(ctx, hipMalloc(&lists, sizeof(unsigned long long) * 257 * (size_t)n_waves));
     hipError_t he = hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream);
     if (he == hipSuccess) {
-        hipLaunchKernelGGL(vd_collect_kernel, dim3(n_waves), dim3(64), 0, ctx->stream, A->val, s, e, lists, overflow);
+        if (!diag) hipLaunchKernelGGL(vd_collect_kernel, dim3(n_waves), dim3(64), 0, ctx->stream, A->val, s, e, lists, overflow);
+        else if (A->rp64) hipLaunchKernelGGL(vd_collect_rows_kernel<int64_t>, dim3(n_waves), dim3(64), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->val, A->n_rows, A->view_row0, lists, overflow);
+        else hipLaunchKernelGGL(vd_collect_rows_kernel<int32_t>, dim3(n_waves), dim3(64), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->val, A->n_rows, A->view_row0, lists, overflow);
         he = hipGetLastError();
     }
     std::vector<unsigned long long> h((size_t)257 * n_waves);
@@ -958,26 +1034,57 @@ bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
     hipFree(lists);
     BIS_HIP_CHECK(ctx, he);
     if (h_over) return BIS_OK;
-    std::vector<unsigned long long> all;
     for (int w = 0; w < n_waves; ++w) {
         const size_t n = (size_t)h[(size_t)w * 257];
-        if (n > 256) return BIS_OK;
-        all.insert(all.end(), h.begin() + (size_t)w * 257 + 1, h.begin() + (size_t)w * 257 + 1 + n);
+        if (n > cap) return BIS_OK;
+        all->insert(all->end(), h.begin() + (size_t)w * 257 + 1, h.begin() + (size_t)w * 257 + 1 + n);
     }
-    std::sort(all.begin(), all.end());
-    all.erase(std::unique(all.begin(), all.end()), all.end());
-    if (all.empty() || all.size() > 256) return BIS_OK;
+    std::sort(all->begin(), all->end());
+    all->erase(std::unique(all->begin(), all->end()), all->end());
+    *ok = all->size() <= cap;
+    return BIS_OK;
+}
+
+static bis_status spmv_try_rowmajor(bis_ctx *ctx, bis_mat *A);
+
+bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
+    if (A->vd_state != 0) return BIS_OK;
+    A->vd_state = -1;
+    if (A->nnz == 0 || A->n_blocks == 0) return BIS_OK;
+    int64_t ends[2];
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[0], A->blk_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&ends[1], A->blk_nnz + A->n_blocks, 8, hipMemcpyDeviceToHost, ctx->stream));
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t s = ends[0], e = ends[1];
+    if (e <= s) return BIS_OK;
+    std::vector<unsigned long long> all;
+    bool ok = false, diag = false;
+    if (bis_status st = vd_collect(ctx, A, s, e, false, &all, &ok)) return st;
+    if (ok && all.empty()) ok = false;
+    if (!ok && spmv_valdict_mode() >= 2 && A->max_row_nnz <= kRmMaxRow && A->n_cols < ((int64_t)1 << 29)) {
+        // few values apart from the diagonal?  (served by the lane-per-row form only: a lane knows its row)
+        if (bis_status st = vd_collect(ctx, A, s, e, true, &all, &ok)) return st;
+        diag = ok;
+    }
+    if (!ok) return BIS_OK;
     unsigned long long table[256] = {};
     std::copy(all.begin(), all.end(), table);
     A->vd_base = s & ~(int64_t)7; // whole 8-byte vectors of codes for the lane-per-row form
     const size_t n_code = (size_t)(e - A->vd_base) + 16;
-    BIS_HIP_CHECK(ctx, hipMalloc(&A->vdict, sizeof table));
-    he = hipMalloc(&A->vcode, n_code);
+    hipError_t he = hipMalloc(&A->vdict, sizeof table);
+    if (he == hipSuccess) he = hipMalloc(&A->vcode, n_code);
+    if (he == hipSuccess && diag) he = hipMalloc(&A->vdiag, sizeof(double) * (size_t)A->n_rows);
     if (he == hipSuccess) he = hipMemsetAsync(A->vcode, 0, n_code, ctx->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(A->vdict, table, sizeof table, hipMemcpyHostToDevice, ctx->stream);
     if (he == hipSuccess) {
-        const int grid = (int)std::min<int64_t>((e - A->vd_base + 1023) / 1024, (int64_t)ctx->n_cus * 32);
-        hipLaunchKernelGGL(vd_encode_kernel, dim3(grid), dim3(256), 0, ctx->stream, A->val, s, e, A->vd_base, A->vdict, (int)all.size(), A->vcode);
+        if (!diag) {
+            const int grid = (int)std::min<int64_t>((e - A->vd_base + 1023) / 1024, (int64_t)ctx->n_cus * 32);
+            hipLaunchKernelGGL(vd_encode_kernel, dim3(grid), dim3(256), 0, ctx->stream, A->val, s, e, A->vd_base, A->vdict, (int)all.size(), A->vcode);
+        } else {
+            const int grid = (int)std::min<int64_t>((A->n_rows + 255) / 256, (int64_t)ctx->n_cus * 32);
+            if (A->rp64) hipLaunchKernelGGL(vd_encode_rows_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->val, A->n_rows, A->view_row0, A->vd_base, A->vdict, (int)all.size(), A->vcode, A->vdiag);
+            else hipLaunchKernelGGL(vd_encode_rows_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->val, A->n_rows, A->view_row0, A->vd_base, A->vdict, (int)all.size(), A->vcode, A->vdiag);
+        }
         he = hipGetLastError();
     }
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream); // table[] lives on this stack frame
@@ -987,7 +1094,12 @@ bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
         BIS_HIP_CHECK(ctx, he);
     }
     A->vd_n = (int)all.size();
+    A->vd_diag = diag;
     A->vd_state = 1;
+    if (diag) { // only the lane-per-row kernel reads this encoding
+        if (bis_status st = spmv_try_rowmajor(ctx, A)) return st;
+        if (A->rm_state != 1) { bis_spmv_drop_valdict(A); A->vd_state = -1; }
+    }
     return BIS_OK;
 }
 
@@ -1052,7 +1164,7 @@ static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArg
     }
     if (a->pk_mode == 1 && spmv_valdict_mode()) { // the value dictionary rides on the packed column stream
         if (bis_status st = bis_spmv_try_valdict(ctx, A)) return st;
-        if (A->vd_state == 1) { a->vcode = A->vcode; a->vd_base = A->vd_base; a->vdict = A->vdict; }
+        if (A->vd_state == 1) { a->vcode = A->vcode; a->vd_base = A->vd_base; a->vdict = A->vdict; a->vd_diag = A->vd_diag; }
     }
     return BIS_OK;
 }
@@ -1075,12 +1187,15 @@ static bis_status launch_rowmajor(bis_ctx *ctx, const bis_mat *A, const SpmvArgs
     const size_t lds = 3 * (size_t)code_cap;
     double *pp = mode == 1 ? partials + partials_off : partials;
     if (mode != 2) bis_prof_begin(ctx);
-#define BIS_RM_LAUNCH(RP, MODE)                                                                                        \
-    hipLaunchKernelGGL((spmv_rowmajor_vd_kernel<RP, MODE>), dim3(grid), dim3(256), lds, ctx->stream, (const RP *)A->row_ptr, x, y, \
-                       A->n_rows, nbr, remap_arg, w, pp, A->rm_pk, A->rm_base, A->rm_seg, a.stop, A->vcode, A->vd_base, A->vdict, code_cap)
+#define BIS_RM_LAUNCH2(RP, MODE, DIAG)                                                                                 \
+    hipLaunchKernelGGL((spmv_rowmajor_vd_kernel<RP, MODE, DIAG>), dim3(grid), dim3(256), lds, ctx->stream, (const RP *)A->row_ptr, x, y, \
+                       A->n_rows, nbr, remap_arg, w, pp, A->rm_pk, A->rm_base, A->rm_seg, a.stop, A->vcode, A->vd_base, A->vdict, code_cap, \
+                       A->vdiag)
+#define BIS_RM_LAUNCH(RP, MODE) do { if (A->vd_diag) BIS_RM_LAUNCH2(RP, MODE, true); else BIS_RM_LAUNCH2(RP, MODE, false); } while (0)
     if (A->rp64) { if (mode == 2) BIS_RM_LAUNCH(int64_t, 2); else if (mode == 1) BIS_RM_LAUNCH(int64_t, 1); else BIS_RM_LAUNCH(int64_t, 0); }
     else { if (mode == 2) BIS_RM_LAUNCH(int32_t, 2); else if (mode == 1) BIS_RM_LAUNCH(int32_t, 1); else BIS_RM_LAUNCH(int32_t, 0); }
 #undef BIS_RM_LAUNCH
+#undef BIS_RM_LAUNCH2
     if (mode != 2) bis_prof_end(ctx);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (mode == 1 && n_partials) *n_partials = nbr * 4;
@@ -1209,7 +1324,7 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
     int f = vd ? 1 : 0;
     if (vd && spmv_valdict_mode() >= 2) {
         if (bis_status st = spmv_try_rowmajor(ctx, const_cast<bis_mat *>(A))) return st;
-        if (A->rm_state == 1) f = 2;
+        if (A->rm_state == 1) f = A->vd_diag ? 3 : 2;
     }
     if (form) *form = f;
     return BIS_OK;

@@ -135,7 +135,10 @@ BIS_API int bis_mat_rp_width(const bis_mat *A);
  * indexes with a 1-byte code per non-zero; n_dict = 0 without a dictionary);
  * form 0 = the CRS-value kernel, 1 = dictionary kernel, consecutive non-zeros
  * per lane, 2 = dictionary kernel, a lane per row with the codes staged through
- * LDS (rows of at most 40 entries, at most 8 column windows per 256 rows).
+ * LDS (rows of at most 40 entries, at most 8 column windows per 256 rows), 3 =
+ * the same with the diagonal entries' values in a per-row array beside the
+ * dictionary (matrices whose off-diagonal values are few but whose diagonal is
+ * not, e.g. the Anderson model: +8 bytes per row).
  * All are lossless re-encodings of the CRS arrays, which stay authoritative:
  * same products, same summation order, bit-identical y.  Option
  * "spmv_valdict" 0 switches the dictionary off, 1 allows form 1 only. */

@@ -960,15 +960,27 @@ def test_spmv_value_dictionary(ctx, oracle, form, rp64):
     streams the CRS values (same products, same summation order) and within the kernel tolerance of the oracle's
     kernels.hpp:22-52 loop.  Both forms of the kernel (1: consecutive non-zeros per lane, 2: a lane per row with the
     codes staged through LDS, the default where rows are short); 2, 256 and 257 distinct values; blocks of
-    empty rows; 64-bit row pointers; a matrix whose values change in place (-scale) drops its dictionary."""
+    empty rows; 64-bit row pointers; a matrix whose values change in place (-scale) drops its dictionary; matrices whose
+    OFF-DIAGONAL values are few while the diagonal is not (Anderson) keep a per-row diagonal array beside the
+    dictionary, unless some row holds two diagonal entries."""
     rng = np.random.default_rng(40 + form)
     ctx.set_option("force_rp64", rp64)
     try:
-        cases = [("hpcg", oracle.gen_hpcg(12, 10, 9), 2), ("anderson W=0", oracle.gen_anderson(9, W=0.0, shift=7.0), 2),
-                 ("256 values", _few_values_matrix(rng, 9000, 256, empty_head=5000), 256),
-                 ("257 values", _few_values_matrix(rng, 3000, 257), 0),
+        dup = oracle.gen_anderson(9, W=5.0, shift=3.0)
+        dup = CRS(dup.n_rows, dup.row_ptr, dup.col.copy(), dup.val)
+        dup.col[dup.row_ptr[100]:dup.row_ptr[100] + 2] = 100  # row 100: two diagonal entries with different values
+        # expected (val_bytes, dictionary values, kernel form) per option value; None: whatever the packing allows
+        d = lambda n: {1: (1, n, 1), 2: (1, n, 2)}
+        diag_only_rowmajor = lambda n: {1: (8, 0, 0), 2: (1, n, 3)}
+        cases = [("hpcg", oracle.gen_hpcg(12, 10, 9), d(2)), ("anderson W=0", oracle.gen_anderson(9, W=0.0, shift=7.0), d(2)),
+                 ("256 values", _few_values_matrix(rng, 9000, 256, empty_head=5000), d(256)),
+                 ("257 values", _few_values_matrix(rng, 3000, 257), {1: (8, 0, 0), 2: (8, 0, 0)}),
+                 # random diagonal, constant hopping: dictionary {-t} + per-row diagonal values (lane-per-row form only)
+                 ("anderson W=5", oracle.gen_anderson(9, W=5.0, shift=3.0), diag_only_rowmajor(1)),
+                 ("anderson 12, W=2", oracle.gen_anderson(12, t=0.5, W=2.0), diag_only_rowmajor(1)),
+                 ("two diagonal entries in a row", dup, {1: (8, 0, 0), 2: (8, 0, 0)}),
                  ("fem", oracle.gen_fem(5, 4, 3), None)]
-        for name, A, want_dict in cases:
+        for name, A, want in cases:
             x = rng.uniform(-1, 1, A.n_cols)
             ys = {}
             for mode in (0, form):
@@ -977,15 +989,14 @@ def test_spmv_value_dictionary(ctx, oracle, form, rp64):
                 col_b, val_b, n_dict, kform = dA.spmv_stream_info()
                 if mode == 0:
                     assert (val_b, n_dict, kform) == (8, 0, 0)
-                elif want_dict is not None and col_b == 2:
-                    assert (val_b, n_dict) == ((1, want_dict) if want_dict else (8, 0)), name
-                    assert kform == (form if want_dict else 0), name  # every dictionary case here has short rows and few windows
+                elif want is not None and col_b == 2:
+                    assert (val_b, n_dict, kform) == want[form], name
                 dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
                 ctx.spmv(dA, dx, dy)
                 ys[mode] = dy.to_host()
                 dA.free(); dx.free(); dy.free()
             assert np.array_equal(ys[0], ys[form], equal_nan=True), name
-            if name != "256 values" and name != "257 values":  # (their huge values overflow to inf/nan in both)
+            if "values" not in name and "entries" not in name:  # (the huge values of those overflow to inf/nan in both)
                 yo = oracle.spmv(A, x)
                 scale = np.abs(A.to_scipy()).dot(np.abs(x)).max()
                 assert np.max(np.abs(ys[form] - yo)) <= KTOL * scale, name
