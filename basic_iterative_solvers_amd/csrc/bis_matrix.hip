@@ -614,6 +614,9 @@ BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_tria
     double best = 0.0;
     if (st == BIS_OK) st = measure(best);
     if (first_ms) *first_ms = best;
+    // the value-dictionary kernels stream a quarter of the bytes and are not HBM-bound: where their arrays lie matters
+    // little, and the arrays re-allocated below (values, packed columns of the row-block tables) are not the ones they read
+    if (A->vd_state == 1) max_trials = 0;
     for (int trial = 0; st == BIS_OK && trial < max_trials; ++trial) {
         Set cand{nullptr, nullptr, nullptr};
         hipError_t e = hipMalloc(&cand.val, sizeof(double) * n_val);
