@@ -545,13 +545,15 @@ def test_vec_gather(ctx):
 
 def test_tune_placement_keeps_the_matrix_intact(ctx, oracle):
     """bis_mat_tune_placement re-allocates the streamed arrays: same SpMV result bit for bit, same
-    CRS download, for the packed stream and for the 32-bit column fallback."""
+    CRS download, for the packed stream and for the 32-bit column fallback (value dictionary off: the kernels that
+    stream the re-allocated arrays), and with the dictionary, where the tuning leaves the matrix as it is."""
     from basic_iterative_solvers_amd import load_library
     lib = load_library()
     A = oracle.gen_hpcg(24)
     x = np.random.default_rng(11).uniform(-1, 1, A.n_rows)
-    for packed in (1, 0):
+    for packed, valdict in ((1, 0), (0, 0), (1, -1)):
         lib.bis_set_option(b"spmv_packed", packed)
+        lib.bis_set_option(b"spmv_valdict", valdict)
         dA = ctx.matrix(A)
         dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
         ctx.spmv(dA, dx, dy)
@@ -564,6 +566,7 @@ def test_tune_placement_keeps_the_matrix_intact(ctx, oracle):
         assert np.array_equal(col, A.col) and np.array_equal(val, A.val)
         dA.free()
     lib.bis_set_option(b"spmv_packed", -1)
+    lib.bis_set_option(b"spmv_valdict", -1)
 
 
 def test_named_kernel_protocol(ctx, oracle):
