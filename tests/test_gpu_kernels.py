@@ -1058,3 +1058,65 @@ def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form):
                 assert np.array_equal(out[0][k], out[form][k]), k
     finally:
         ctx.set_option("spmv_valdict", -1)
+
+
+def test_value_dictionary_kernel_selection_and_shapes(ctx, oracle):
+    """Which dictionary kernel a matrix gets (bis_mat_spmv_stream_info) and that every choice computes the same y as
+    the CRS-value kernel, bit for bit: rows longer than the lane-per-row form's 40 entries -> consecutive form;
+    rectangular matrices (more columns than rows: a rank's [owned | halo] numbering) in both encodings; row counts
+    that are not a multiple of the 256-row blocks; a single row; columns scattered over more windows than the packed
+    stream has -> no packing, no dictionary."""
+    rng = np.random.default_rng(77)
+
+    def banded(n, n_cols, width, lens, values, diag_random=False):
+        rp = np.concatenate([[0], np.cumsum(lens)])
+        col = np.empty(rp[-1], dtype=np.int32)
+        val = np.empty(rp[-1])
+        for r in range(n):
+            k0, k1 = rp[r], rp[r + 1]
+            c = rng.choice(np.arange(max(0, r - width), min(n_cols, r + width + 1)), size=k1 - k0, replace=False)
+            if diag_random and r not in c:
+                c[0] = r  # every row has its diagonal entry
+            c = np.sort(c)
+            col[k0:k1] = c
+            val[k0:k1] = rng.choice(values, size=k1 - k0)
+            if diag_random:
+                hit = np.nonzero(c == r)[0]
+                val[k0 + hit] = rng.uniform(1, 2, len(hit))
+        return CRS(n, rp, col, val, n_cols=n_cols)
+
+    vals = np.array([-1.0, 0.5, 26.0])
+    n = 1000
+    cases = [
+        ("rows of 41", banded(n, n, 60, np.full(n, 41), vals), (1, 3, 1)),
+        ("rows of 40", banded(n, n, 60, np.full(n, 40), vals), (1, 3, 2)),
+        ("rectangular", banded(n, n + 300, 30, rng.integers(1, 20, n), vals), (1, 3, 2)),
+        ("rectangular, random diagonal", banded(n, n + 300, 30, rng.integers(3, 20, n), vals, diag_random=True), None),
+        ("777 rows", banded(777, 777, 20, rng.integers(0, 15, 777), vals), (1, 3, 2)),
+        ("one row", CRS(1, [0, 2], [0, 0], [2.0, 3.0]), (1, 2, 2)),
+        ("scattered columns", CRS(600, np.arange(0, 601 * 9, 9), rng.integers(0, 200000, 5400).astype(np.int32),
+                                  rng.choice(vals, 5400), n_cols=200000), None),
+    ]
+    try:
+        for name, A, want in cases:
+            x = rng.uniform(-1, 1, A.n_cols)
+            ys = {}
+            for mode in (0, -1):
+                ctx.set_option("spmv_valdict", mode)
+                dA = ctx.matrix(A)
+                info = dA.spmv_stream_info()
+                if mode == -1 and want is not None and info[0] == 2:
+                    assert info[1:] == want, (name, info)
+                if mode == -1 and name == "rectangular, random diagonal":
+                    assert info[0] != 2 or info[1:] == (1, 3, 3), info
+                if name == "scattered columns":
+                    assert info == (4, 8, 0, 0), info
+                dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
+                ctx.spmv(dA, dx, dy)
+                ys[mode] = dy.to_host()
+                dA.free(); dx.free(); dy.free()
+            assert np.array_equal(ys[0], ys[-1]), name
+            yo = oracle.spmv(A, x)
+            assert np.max(np.abs(ys[-1] - yo)) <= KTOL * max(np.abs(A.to_scipy()).dot(np.abs(x)).max(), 1e-300), name
+    finally:
+        ctx.set_option("spmv_valdict", -1)
