@@ -134,13 +134,14 @@ struct bis_mat {
     // row's diagonal value", kept in a per-row array (Anderson: random diagonal, constant hopping).  Lane-per-row form only.
     double *vdiag = nullptr;   // [n_rows] when vd_diag
     bool vd_diag = false;
+    bool vd_rm_only = false;   // only the lane-per-row kernel can use this dictionary (vd_diag, or the row-block tables have no packed columns)
     int64_t view_row0 = 0;     // row views: first row of the view in the matrix it was cut from
     // lane-per-row form of the dictionary kernel: blocks of 256 rows with their own packed column stream
     int64_t *rm_nnz = nullptr;  // [rm_blocks + 1] row_ptr at every 256th row
     uint16_t *rm_pk = nullptr;  // column codes against rm_seg's windows, index k - rm_base
     int32_t *rm_seg = nullptr;  // [rm_blocks * 8]
     int64_t rm_base = 0;
-    int rm_state = 0, rm_blocks = 0;
+    int rm_state = 0, rm_blocks = 0, rm_kind = 1; // rm_kind 1: 8 windows x 8192 columns per block, 3: 32 windows x 2048 columns
     // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
     int32_t *blkf_row = nullptr;
     int64_t *blkf_nnz = nullptr;
@@ -268,7 +269,7 @@ bis_status bis_mat_finalize(bis_ctx *ctx, bis_mat *A);
 bis_status bis_spmv_build_window(bis_ctx *ctx, bis_mat *A);
 void bis_spmv_drop_packed(bis_mat *A);
 void bis_spmv_drop_valdict(bis_mat *A); // after the values of A changed in place
-bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A);
+bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A, bool consecutive_ok);
 // try to build the packed-column stream of table t (0 plain, 1 fused); A->pk_state[t] tells the outcome
 bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t);
 // free row-block tables, packed streams and window structures (not the CRS arrays)

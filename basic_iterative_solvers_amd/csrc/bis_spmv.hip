@@ -397,7 +397,9 @@ __device__ __forceinline__ int wave_min_i(int v) {
 
 // DIAG: value code 255 stands for the row's own diagonal value vdiag[row] (matrices whose off-diagonal values are few
 // but whose diagonal is not: Anderson's random potential).
-template <typename RP, int MODE, bool DIAG>
+// W32: the block's columns are coded against 32 windows of 2048 columns (lane j < 32 of every wave holds base j) instead
+// of 8 windows of 8192: multi-colour-permuted matrices, whose rows reach into a dozen or more short column runs.
+template <typename RP, int MODE, bool DIAG, bool W32>
 __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
     const RP *__restrict__ row_ptr, const double *x, double *y, int64_t n_rows, int n_blocks, int n_blocks_pad8,
     const double *w, double *partials, const uint16_t *__restrict__ pk, int64_t pk_base, const int32_t *__restrict__ seg_base,
@@ -436,7 +438,8 @@ __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
         len = (int)((int64_t)row_ptr[r0 + threadIdx.x + 1] - ra);
         if (DIAG) dval = vdiag[r0 + threadIdx.x];
     }
-    const int lane_base = seg_base[(size_t)b * 8 + (threadIdx.x & 7)];
+    constexpr int SEGS = W32 ? kPk3Segs : kPkSegs, OFFBITS = W32 ? kPk3OffBits : kPkOffBits;
+    const int lane_base = seg_base[(size_t)b * SEGS + (threadIdx.x & (SEGS - 1))];
     const char *xb = reinterpret_cast<const char *>(x);
     __syncthreads();
     double acc = 0.0;
@@ -449,8 +452,8 @@ __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
             // ragged tail: lanes past their row's end re-read the block's first code; their product is dropped
             const int idx = (whole || j0 + q < len) ? a + j0 + q : first;
             const unsigned code = lpk[idx];
-            const int wbase = __builtin_amdgcn_ds_bpermute((int)((code >> (kPkOffBits - 2)) & 28u), lane_base);
-            xx[q] = x_at<false>(xb, wbase + (int)(code & (kPkSpan - 1)));
+            const int wbase = __builtin_amdgcn_ds_bpermute((int)((code >> (OFFBITS - 2)) & (unsigned)((SEGS - 1) * 4)), lane_base);
+            xx[q] = x_at<false>(xb, wbase + (int)(code & ((1u << OFFBITS) - 1)));
             const unsigned vcd = lvc[idx];
             vv[q] = dict[vcd];
             if (DIAG) vv[q] = vcd == 255u ? dval : vv[q];
@@ -827,7 +830,7 @@ struct SpmvArgs {
     bool wide = false; // 2^29 columns or more: 64-bit x addressing, 32-bit column stream
     const int *stop = nullptr;
     const uint8_t *vcode = nullptr; int64_t vd_base = 0; const double *vdict = nullptr; // value dictionary (pk_mode 1 only)
-    bool vd_diag = false; // code 255 = the row's diagonal value: lane-per-row kernel only
+    bool vd_rm_only = false; // lane-per-row kernel only
 };
 
 template <typename RP, int T, int U, int BR = 0>
@@ -862,7 +865,7 @@ void launch_vd(const SpmvArgs &a) {
 
 template <typename RP>
 bool launch_by_id(int id, const SpmvArgs &a) {
-    if (a.vcode && !a.vd_diag && id == 20 && a.pk_mode == 1) { // value dictionary: the default form only
+    if (a.vcode && !a.vd_rm_only && id == 20 && a.pk_mode == 1) { // value dictionary, consecutive form: the default variant only
         if (a.mode == 2) launch_vd<RP, 2>(a);
         else if (a.mode == 1) launch_vd<RP, 1>(a);
         else launch_vd<RP, 0>(a);
@@ -988,17 +991,24 @@ static bis_status spmv_try_rowmajor(bis_ctx *ctx, bis_mat *A) {
     if (A->rm_base < A->vd_base) return BIS_OK; // (both are the first row's start rounded down: cannot happen)
     const size_t n_pk = (size_t)(ends[1] - A->rm_base) + 16;
     BIS_HIP_CHECK(ctx, hipMalloc(&A->rm_pk, sizeof(uint16_t) * n_pk));
-    BIS_HIP_CHECK(ctx, hipMalloc(&A->rm_seg, sizeof(int32_t) * (size_t)nb * 8));
+    BIS_HIP_CHECK(ctx, hipMalloc(&A->rm_seg, sizeof(int32_t) * (size_t)nb * kPk3Segs));
     int *status = (int *)ctx->counters + 47;
-    BIS_HIP_CHECK(ctx, hipMemsetAsync(A->rm_pk, 0, sizeof(uint16_t) * n_pk, ctx->stream));
-    BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL((pk_build_kernel<kPkSegs, kPkOffBits>), dim3(nb), dim3(256), 0, ctx->stream, A->col, A->rm_nnz, nb, A->rm_base,
-                       A->rm_pk, A->rm_seg, status);
-    BIS_HIP_CHECK(ctx, hipGetLastError());
-    int h = 0;
-    BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h) { // some block of 256 rows needs a ninth column window: the consecutive form stays
+    int h = 1;
+    for (int kind = 1; kind <= 3 && h; kind += 2) {
+        BIS_HIP_CHECK(ctx, hipMemsetAsync(A->rm_pk, 0, sizeof(uint16_t) * n_pk, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
+        if (kind == 1)
+            hipLaunchKernelGGL((pk_build_kernel<kPkSegs, kPkOffBits>), dim3(nb), dim3(256), 0, ctx->stream, A->col, A->rm_nnz, nb, A->rm_base,
+                               A->rm_pk, A->rm_seg, status);
+        else
+            hipLaunchKernelGGL((pk_build_kernel<kPk3Segs, kPk3OffBits>), dim3(nb), dim3(256), 0, ctx->stream, A->col, A->rm_nnz, nb, A->rm_base,
+                               A->rm_pk, A->rm_seg, status);
+        BIS_HIP_CHECK(ctx, hipGetLastError());
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(&h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!h) A->rm_kind = kind;
+    }
+    if (h) { // some block of 256 rows needs more column windows than either format has: the other kernels stay
         hipFree(A->rm_nnz); hipFree(A->rm_pk); hipFree(A->rm_seg);
         A->rm_nnz = nullptr; A->rm_pk = nullptr; A->rm_seg = nullptr;
         return BIS_OK;
@@ -1050,7 +1060,7 @@ static bis_status vd_collect(bis_ctx *ctx, const bis_mat *A, int64_t s, int64_t 
 
 static bis_status spmv_try_rowmajor(bis_ctx *ctx, bis_mat *A);
 
-bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
+bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A, bool consecutive_ok) {
     if (A->vd_state != 0) return BIS_OK;
     A->vd_state = -1;
     if (A->nnz == 0 || A->n_blocks == 0) return BIS_OK;
@@ -1064,7 +1074,9 @@ bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
     bool ok = false, diag = false;
     if (bis_status st = vd_collect(ctx, A, s, e, false, &all, &ok)) return st;
     if (ok && all.empty()) ok = false;
-    if (!ok && spmv_valdict_mode() >= 2 && A->max_row_nnz <= kRmMaxRow && A->n_cols < ((int64_t)1 << 29)) {
+    const bool rm_possible = spmv_valdict_mode() >= 2 && A->max_row_nnz <= kRmMaxRow && A->n_cols < ((int64_t)1 << 29);
+    if (!consecutive_ok && !rm_possible) return BIS_OK;
+    if (!ok && rm_possible) {
         // few values apart from the diagonal?  (served by the lane-per-row form only: a lane knows its row)
         if (bis_status st = vd_collect(ctx, A, s, e, true, &all, &ok)) return st;
         diag = ok;
@@ -1098,8 +1110,9 @@ bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A) {
     }
     A->vd_n = (int)all.size();
     A->vd_diag = diag;
+    A->vd_rm_only = diag || !consecutive_ok;
     A->vd_state = 1;
-    if (diag) { // only the lane-per-row kernel reads this encoding
+    if (A->vd_rm_only) { // only the lane-per-row kernel can use it: does the matrix qualify?
         if (bis_status st = spmv_try_rowmajor(ctx, A)) return st;
         if (A->rm_state != 1) { bis_spmv_drop_valdict(A); A->vd_state = -1; }
     }
@@ -1165,9 +1178,10 @@ static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArg
         a->col_max = (int)std::max<int64_t>(A->n_cols - 1, 0);
         a->pk_mode = A->pk_kind[t] == 3 ? 3 : (spmv_packed_mode() == 2 ? 2 : 1);
     }
-    if (a->pk_mode == 1 && spmv_valdict_mode()) { // the value dictionary rides on the packed column stream
-        if (bis_status st = bis_spmv_try_valdict(ctx, A)) return st;
-        if (A->vd_state == 1) { a->vcode = A->vcode; a->vd_base = A->vd_base; a->vdict = A->vdict; a->vd_diag = A->vd_diag; }
+    if (spmv_valdict_mode()) { // value dictionary: the consecutive kernel rides on the packed stream of the row-block table,
+                               // the lane-per-row kernel brings its own
+        if (bis_status st = bis_spmv_try_valdict(ctx, A, a->pk_mode == 1)) return st;
+        if (A->vd_state == 1) { a->vcode = A->vcode; a->vd_base = A->vd_base; a->vdict = A->vdict; a->vd_rm_only = A->vd_rm_only; }
     }
     return BIS_OK;
 }
@@ -1176,7 +1190,7 @@ static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArg
 static bis_status launch_rowmajor(bis_ctx *ctx, const bis_mat *A, const SpmvArgs &a, const double *x, double *y, int mode,
                                   const double *w, double *partials, size_t partials_off, int *n_partials, bool *done) {
     *done = false;
-    if (!(a.vcode && spmv_valdict_mode() >= 2 && spmv_variant(a) == 20 && a.pk_mode == 1)) return BIS_OK;
+    if (!(a.vcode && spmv_valdict_mode() >= 2 && (bis_opts().spmv_variant < 0 || bis_opts().spmv_variant == 20))) return BIS_OK;
     if (bis_status st = spmv_try_rowmajor(ctx, const_cast<bis_mat *>(A))) return st;
     if (A->rm_state != 1) return BIS_OK;
     const int nbr = A->rm_blocks, nbr8 = (nbr + 7) & ~7;
@@ -1190,15 +1204,17 @@ static bis_status launch_rowmajor(bis_ctx *ctx, const bis_mat *A, const SpmvArgs
     const size_t lds = 3 * (size_t)code_cap;
     double *pp = mode == 1 ? partials + partials_off : partials;
     if (mode != 2) bis_prof_begin(ctx);
-#define BIS_RM_LAUNCH2(RP, MODE, DIAG)                                                                                 \
-    hipLaunchKernelGGL((spmv_rowmajor_vd_kernel<RP, MODE, DIAG>), dim3(grid), dim3(256), lds, ctx->stream, (const RP *)A->row_ptr, x, y, \
+#define BIS_RM_LAUNCH3(RP, MODE, DIAG, W32)                                                                            \
+    hipLaunchKernelGGL((spmv_rowmajor_vd_kernel<RP, MODE, DIAG, W32>), dim3(grid), dim3(256), lds, ctx->stream, (const RP *)A->row_ptr, x, y, \
                        A->n_rows, nbr, remap_arg, w, pp, A->rm_pk, A->rm_base, A->rm_seg, a.stop, A->vcode, A->vd_base, A->vdict, code_cap, \
                        A->vdiag)
+#define BIS_RM_LAUNCH2(RP, MODE, DIAG) do { if (A->rm_kind == 3) BIS_RM_LAUNCH3(RP, MODE, DIAG, true); else BIS_RM_LAUNCH3(RP, MODE, DIAG, false); } while (0)
 #define BIS_RM_LAUNCH(RP, MODE) do { if (A->vd_diag) BIS_RM_LAUNCH2(RP, MODE, true); else BIS_RM_LAUNCH2(RP, MODE, false); } while (0)
     if (A->rp64) { if (mode == 2) BIS_RM_LAUNCH(int64_t, 2); else if (mode == 1) BIS_RM_LAUNCH(int64_t, 1); else BIS_RM_LAUNCH(int64_t, 0); }
     else { if (mode == 2) BIS_RM_LAUNCH(int32_t, 2); else if (mode == 1) BIS_RM_LAUNCH(int32_t, 1); else BIS_RM_LAUNCH(int32_t, 0); }
 #undef BIS_RM_LAUNCH
 #undef BIS_RM_LAUNCH2
+#undef BIS_RM_LAUNCH3
     if (mode != 2) bis_prof_end(ctx);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (mode == 1 && n_partials) *n_partials = nbr * 4;
@@ -1320,15 +1336,15 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
     const int64_t lds_doubles = (int64_t)A->chunk_nnz + A->max_row_nnz + 8;
     if (A->n_rows > 0 && sizeof(double) * (size_t)lds_doubles <= 64 * 1024 && !(A->win_ok && spmv_window_mode()))
         if (bis_status st = ensure_packed(ctx, A, 0, &a)) return st;
-    const bool vd = a.vcode && spmv_variant(a) == 20 && a.pk_mode == 1;
-    if (col_bytes) *col_bytes = a.pk_mode ? 2 : 4;
-    if (val_bytes) *val_bytes = vd ? 1 : 8;
-    if (n_dict) *n_dict = vd ? A->vd_n : 0;
-    int f = vd ? 1 : 0;
-    if (vd && spmv_valdict_mode() >= 2) {
+    int f = 0;
+    if (a.vcode && spmv_valdict_mode() >= 2 && (bis_opts().spmv_variant < 0 || bis_opts().spmv_variant == 20)) {
         if (bis_status st = spmv_try_rowmajor(ctx, const_cast<bis_mat *>(A))) return st;
         if (A->rm_state == 1) f = A->vd_diag ? 3 : 2;
     }
+    if (!f && a.vcode && !a.vd_rm_only && spmv_variant(a) == 20 && a.pk_mode == 1) f = 1;
+    if (col_bytes) *col_bytes = (f >= 2 || a.pk_mode) ? 2 : 4;
+    if (val_bytes) *val_bytes = f ? 1 : 8;
+    if (n_dict) *n_dict = f ? A->vd_n : 0;
     if (form) *form = f;
     return BIS_OK;
 }

@@ -1047,9 +1047,16 @@ def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form):
             xf, xb = ctx.alloc(n), ctx.alloc(n)
             ctx.sptrsv(Ls, xf, D, rhs)
             ctx.bsptrsv(Us, xb, D, rhs)
-            out[mode] = (np.array(hist), x.to_host(), xf.to_host(), xb.to_host(), dA.spmv_stream_info())
+            yB = ctx.alloc(n)
+            ctx.spmv(B, rhs, yB)  # the permuted matrix: its rows reach into too many column runs for the 8-window packing
+            out[mode] = (np.array(hist), x.to_host(), xf.to_host(), xb.to_host(), dA.spmv_stream_info(), yB.to_host(),
+                         B.spmv_stream_info())
             cg.free()
         assert out[0][4][1:] == (8, 0, 0) and out[form][4][1:] == (1, 2, form)
+        assert out[0][6][1:] == (8, 0, 0)
+        if form == 2:  # the lane-per-row kernel brings its own packing (32 windows of 2048 columns where 8 x 8192 do not do)
+            assert out[form][6] == (2, 1, 2, 2)
+        assert np.array_equal(out[0][5], out[form][5])
         for k in range(4):
             if form == 2 and k < 2:
                 tol = 1e-12 * out[0][0][0] if k == 0 else 1e-10 * np.max(np.abs(out[0][1]))
