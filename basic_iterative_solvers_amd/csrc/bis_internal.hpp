@@ -156,6 +156,9 @@ struct bis_mat {
     // triangular-solve plans (built lazily)
     bis_trsv_plan *plan_fwd = nullptr;
     bis_trsv_plan *plan_bwd = nullptr;
+    // the tiled natural-order sweep's plans (bis_trsv_tiled.hip), tried first: where they exist no level analysis is made
+    struct bis_trsv_tiled *tiled_fwd = nullptr, *tiled_bwd = nullptr;
+    bool tiled_tried_fwd = false, tiled_tried_bwd = false;
 };
 
 #define BIS_HIP_CHECK(ctx, call)                                               \

@@ -51,9 +51,6 @@ struct bis_trsv_plan {
     // few-level orderings whose levels are contiguous row ranges: one row view per level
     std::vector<bis_mat *> level_views;
     std::vector<int64_t> level_row0;
-    // natural orderings: the tiled sweep (bis_trsv_tiled.hip), built at the first solve
-    bis_trsv_tiled *tiled = nullptr;
-    bool tiled_tried = false;
 };
 
 void bis_trsv_plan_destroy(bis_trsv_plan *p) {
@@ -62,7 +59,6 @@ void bis_trsv_plan_destroy(bis_trsv_plan *p) {
     hipFree(p->xs);
     hipFree(p->pcol);
     hipFree(p->ticket);
-    bis_trsv_tiled_destroy(p->tiled);
     for (bis_mat *v : p->level_views) { // row views: only their block tables are theirs
         bis_mat_free_meta(v);
         delete v;
@@ -499,6 +495,19 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     BIS_REQUIRE(ctx, T->n_rows == T->n_cols, "sptrsv: square matrix required");
     const int64_t n = T->n_rows;
     if (n == 0) return BIS_OK;
+    // natural orderings on a grid: the tiled sweep (modes: bis_trsv_tiled_build), tried first -- its plan
+    // checks the dependency order itself, so where it applies the level analysis below is never made
+    if (bis_opts().trsv_tiled != 0 && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_one_xcd <= 0) {
+        bis_mat *M = const_cast<bis_mat *>(T);
+        bis_trsv_tiled *&ts = backward ? M->tiled_bwd : M->tiled_fwd;
+        bool &tried = backward ? M->tiled_tried_bwd : M->tiled_tried_fwd;
+        if (!tried) {
+            tried = true;
+            const bis_status tst = bis_trsv_tiled_build(ctx, T, backward, &ts);
+            if (tst != BIS_OK) return tst;
+        }
+        if (ts) return bis_trsv_tiled_solve(ctx, ts, x, D, b);
+    }
     bis_trsv_plan *p = nullptr;
     bis_status st = get_plan(ctx, T, backward, &p);
     if (st != BIS_OK) return st;
@@ -523,14 +532,6 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
         }
         BIS_HIP_CHECK(ctx, hipGetLastError());
         return BIS_OK;
-    }
-    if (bis_opts().trsv_tiled != 0 && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_one_xcd <= 0) { // DESIGN.md section 4; modes: bis_trsv_tiled_build
-        if (!p->tiled_tried) {
-            p->tiled_tried = true;
-            st = bis_trsv_tiled_build(ctx, T, backward, &p->tiled);
-            if (st != BIS_OK) return st;
-        }
-        if (p->tiled) return bis_trsv_tiled_solve(ctx, p->tiled, x, D, b);
     }
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,
