@@ -142,6 +142,48 @@ __global__ __launch_bounds__(kEwThreads) void dot_partial_kernel(const double *a
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// Fused step of the modified Gram-Schmidt loop (gmres.hpp:10-27): w -= s * u, then partials of (w, v) over the UPDATED w
+// in the same pass (v == nullptr: (w, w), gmres.hpp:36-38).  Index map, accumulators and block sums are those of
+// ew3_kernel<OP_SUB> followed by dot_partial_kernel: same bits as the two separate launches.
+template <bool VEC>
+__global__ __launch_bounds__(kEwThreads) void axpy_dot_kernel(double *w, const double *u, const double *v, int64_t n,
+                                                              const double *s_dev, double *partials) {
+    __shared__ double lds[kEwThreads / 64];
+    const double s = *s_dev;
+    const int64_t stride = (int64_t)gridDim.x * kEwThreads;
+    int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (VEC) {
+        const int64_t n2 = n >> 1;
+        double2 *w2 = reinterpret_cast<double2 *>(w);
+        const double2 *u2 = reinterpret_cast<const double2 *>(u);
+        const double2 *v2 = reinterpret_cast<const double2 *>(v);
+        for (; i < n2; i += stride) {
+            double2 wv = w2[i];
+            const double2 uv = u2[i];
+            wv.x = ew_apply<OP_SUB>(wv.x, uv.x, s);
+            wv.y = ew_apply<OP_SUB>(wv.y, uv.y, s);
+            w2[i] = wv;
+            const double2 vv = v ? v2[i] : wv;
+            acc0 = fma(wv.x, vv.x, acc0);
+            acc1 = fma(wv.y, vv.y, acc1);
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const double t = ew_apply<OP_SUB>(w[n - 1], u[n - 1], s);
+            w[n - 1] = t;
+            acc0 = fma(t, v ? v[n - 1] : t, acc0);
+        }
+    } else {
+        for (; i < n; i += stride) {
+            const double t = ew_apply<OP_SUB>(w[i], u[i], s);
+            w[i] = t;
+            acc0 = fma(t, v ? v[i] : t, acc0);
+        }
+    }
+    const double r = block_sum<kEwThreads>(acc0 + acc1, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 // result[v] = sum_i partials[v*stride + i], fixed order.
 __global__ __launch_bounds__(256) void reduce_finish_kernel(const double *partials,
                                                             int n_partials, size_t stride,
@@ -509,6 +551,26 @@ bis_status bis_dot_dev(bis_ctx *ctx, const double *a, const double *b, int64_t n
     else
         hipLaunchKernelGGL((dot_partial_kernel<false>), dim3(grid), dim3(kEwThreads), 0,
                            ctx->stream, a, b, n, ctx->partials);
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return bis_reduce_finish(ctx, grid, 1, 0, result_dev);
+}
+
+bis_status bis_axpy_dot_dev(bis_ctx *ctx, double *w, const double *u, const double *scale_dev, const double *v, int64_t n,
+                            double *result_dev) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, n >= 0 && result_dev && scale_dev && (n == 0 || (w && u)), "bis_axpy_dot_dev: bad arguments");
+    BIS_REQUIRE(ctx, w != u && w != v, "bis_axpy_dot_dev: w must not alias u or v (pass v = NULL for (w, w))");
+    // bit-identical to the separate launches only if both of them would take the same form (16-byte vector or scalar
+    // index map); with mixed alignment (odd n: every other basis vector) they would not: run them separately then
+    const bool vec_axpy = aligned16(w) && aligned16(u) && n >= 2, vec_dot = aligned16(w) && (!v || aligned16(v)) && n >= 2;
+    if (vec_axpy != vec_dot) {
+        const bis_status st = bis_subtract_vectors_dev(ctx, w, w, u, n, scale_dev);
+        return st != BIS_OK ? st : bis_dot_dev(ctx, w, v ? v : w, n, result_dev);
+    }
+    const bool vec = vec_axpy;
+    const int grid = n == 0 ? 1 : (vec ? ew_grid(n >> 1) : ew_grid(n));
+    if (vec) hipLaunchKernelGGL((axpy_dot_kernel<true>), dim3(grid), dim3(kEwThreads), 0, ctx->stream, w, u, v, n, scale_dev, ctx->partials);
+    else hipLaunchKernelGGL((axpy_dot_kernel<false>), dim3(grid), dim3(kEwThreads), 0, ctx->stream, w, u, v, n, scale_dev, ctx->partials);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return bis_reduce_finish(ctx, grid, 1, 0, result_dev);
 }

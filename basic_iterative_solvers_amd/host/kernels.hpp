@@ -98,6 +98,9 @@ inline void apply_preconditioner(const PrecondType pc, const int N, const Matrix
 inline void dot_dev(const double *a, const double *b, const int N, double *result_dev) {
     bis::check(bis_dot_dev(bis::ctx(), a, b, N, result_dev), "dot_dev");
 }
+inline void axpy_dot_dev(double *w, const double *u, const double *scale_dev, const double *v, const int N, double *result_dev) {
+    bis::check(bis_axpy_dot_dev(bis::ctx(), w, u, scale_dev, v, N, result_dev), "axpy_dot_dev");
+}
 inline void subtract_vectors_dev(double *r, const double *a, const double *b, const int N, const double *scale_dev) {
     bis::check(bis_subtract_vectors_dev(bis::ctx(), r, a, b, N, scale_dev), "subtract_vectors_dev");
 }

@@ -311,6 +311,13 @@ BIS_API bis_status bis_sumsq_dev(bis_ctx *ctx, const double *v, int64_t n,
  * (bicgstab.hpp:8-83): alpha, omega, beta stay on the device.  Same kernels,
  * same IEEE operations in the same order as the host-scalar forms: results
  * are bit-identical to them. */
+/* One pass for "w -= (*scale_dev) * u; *result_dev = (w, v)" -- the axpy of
+ * Gram-Schmidt step j fused with the dot of step j+1 (gmres.hpp:13-14,:25), or,
+ * with v = NULL, with the sum of squares of the finished w (:36-38).  Bit-
+ * identical to bis_subtract_vectors_dev followed by bis_dot_dev. */
+BIS_API bis_status bis_axpy_dot_dev(bis_ctx *ctx, double *w, const double *u,
+                                    const double *scale_dev, const double *v,
+                                    int64_t n, double *result_dev);
 BIS_API bis_status bis_subtract_vectors_dev(bis_ctx *ctx, double *r, const double *a,
                                             const double *b, int64_t n,
                                             const double *scale_dev);

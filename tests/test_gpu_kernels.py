@@ -1127,3 +1127,29 @@ def test_value_dictionary_kernel_selection_and_shapes(ctx, oracle):
             assert np.max(np.abs(ys[-1] - yo)) <= KTOL * max(np.abs(A.to_scipy()).dot(np.abs(x)).max(), 1e-300), name
     finally:
         ctx.set_option("spmv_valdict", -1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 777, 4096, 100001, 1 << 20])
+def test_fused_axpy_dot_is_bit_identical_to_the_separate_kernels(ctx, n):
+    """bis_axpy_dot_dev (the modified Gram-Schmidt axpy of step j fused with the dot of step j+1, gmres.hpp:13-14,:25,
+    and with the sum of squares, :36-38): same w and the same reduction value, bit for bit, as
+    bis_subtract_vectors_dev followed by bis_dot_dev -- for even and odd n and for basis vectors at odd offsets
+    (V + j n with odd n: every other vector is only 8-byte aligned)."""
+    import ctypes as C
+    lib = ctx.lib
+    rng = np.random.default_rng(n)
+    V = ctx.upload(rng.uniform(-1, 1, 3 * n + 1))
+    w0 = rng.uniform(-1, 1, n)
+    sc = ctx.upload(np.array([0.37, 0.0, 0.0]))
+    p = lambda vec, off=0: C.c_void_p(vec.ptr + 8 * off)
+    for u_off, v_off in ((0, n), (n, 2 * n), (1, n + 1), (0, None)):
+        wa, wb = ctx.upload(w0), ctx.upload(w0)
+        vp = p(V, v_off) if v_off is not None else None
+        ctx.check(lib.bis_subtract_vectors_dev(ctx.h, p(wa), p(wa), p(V, u_off), C.c_int64(n), p(sc)))
+        ctx.check(lib.bis_dot_dev(ctx.h, p(wa), vp if vp is not None else p(wa), C.c_int64(n), p(sc, 1)))
+        ctx.check(lib.bis_axpy_dot_dev(ctx.h, p(wb), p(V, u_off), p(sc), vp, C.c_int64(n), p(sc, 2)))
+        ctx.sync()
+        s = sc.to_host()
+        assert np.array_equal(wa.to_host(), wb.to_host())
+        assert s[1] == s[2] and np.isfinite(s[1])
+        wa.free(); wb.free()
