@@ -3,7 +3,8 @@
 //   * cg_separate_iteration: the reference's kernel-by-kernel order
 //     (cg.hpp:6-54), three blocking dots per iteration;
 //   * the fused device schedule (bis_cg_*: three streaming passes, alpha/beta
-//     and the stop test on the device) -- the default for -p none / -p j.
+//     and the stop test on the device) -- the default; -p none / -p j inside its
+//     update pass, every other preconditioner through bis_cg_set_preconditioner.
 #pragma once
 
 #include "../solver.hpp"
@@ -36,7 +37,7 @@ class ConjugateGradientSolver : public Solver {
     std::vector<double> fused_hist;
 
     explicit ConjugateGradientSolver(const Args *a) : Solver(a) {
-        fused = !a->unfused && (preconditioner == PrecondType::None || preconditioner == PrecondType::Jacobi);
+        fused = !a->unfused; // every preconditioner: None / Jacobi inside pass B, the others through bis_cg_set_preconditioner
     }
     void allocate_structs(const int n) override {
         Solver::allocate_structs(n);
@@ -53,6 +54,10 @@ class ConjugateGradientSolver : public Solver {
         if (fused) {
             bis::check(bis_cg_create(bis::ctx(), A->dev, preconditioner == PrecondType::Jacobi ? A_D : nullptr,
                                      b, x_old, &fcg), "bis_cg_create");
+            if (preconditioner != PrecondType::None && preconditioner != PrecondType::Jacobi)
+                bis::check(bis_cg_set_preconditioner(bis::ctx(), fcg, (int)preconditioner, L_strict ? L_strict->dev : nullptr,
+                                                     U_strict ? U_strict->dev : nullptr, A_D, A_D_inv, L_D, U_D,
+                                                     PRECOND_OUTER_ITERS, PRECOND_INNER_ITERS), "bis_cg_set_preconditioner");
             bis::check(bis_cg_init(bis::ctx(), fcg, tolerance, &residual_norm), "bis_cg_init");
             collected_residual_norms[collected_residual_norms_count++] = residual_norm;
             return;
@@ -71,11 +76,13 @@ class ConjugateGradientSolver : public Solver {
             // updating at the reference's stopping iteration (bis_cg.hip)
             if (fused_hist.empty()) {
                 // chunks of 50 iterations with a status read in between: passes enqueued
-                // behind the stopping iteration are no-ops, but they are still launches
+                // behind the stopping iteration are no-ops, but they are still launches -- and the
+                // sweeps of a general preconditioner do not see the stop flag at all: chunks of 8 there
+                const bool sweeps = preconditioner != PrecondType::None && preconditioner != PrecondType::Jacobi;
                 int it = 0, conv = 0, enq = 0;
                 fused_hist.assign(1, 0.0);
                 while (enq < max_iters) {
-                    const int batch = std::min(50, max_iters - enq);
+                    const int batch = std::min(sweeps ? 8 : 50, max_iters - enq);
                     TIME(timers, "spmv", bis::check(bis_cg_iterate(bis::ctx(), fcg, batch), "bis_cg_iterate"))
                     enq += batch;
                     fused_hist.resize(enq + 1);
