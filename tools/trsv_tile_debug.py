@@ -12,7 +12,7 @@ kind, n1 = sys.argv[1], int(sys.argv[2])
 ctx = Context(0)
 if len(sys.argv) > 3: ctx.set_option("trsv_tile_rows", int(sys.argv[3]))
 if len(sys.argv) > 4: ctx.set_option("trsv_tile_edge", int(sys.argv[4]))
-ctx.set_option("trsv_tiled", 1)
+ctx.set_option("trsv_tiled", int(os.environ.get("TILED_MODE", "-1")))
 A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_fem(n1) if kind == "fem" else ctx.gen_anderson(n1, shift=9.0)
 Ls, Us, D, Dinv = ctx.split_strict(A)
 N = A.n_rows
