@@ -1153,3 +1153,68 @@ def test_fused_axpy_dot_is_bit_identical_to_the_separate_kernels(ctx, n):
         assert np.array_equal(wa.to_host(), wb.to_host())
         assert s[1] == s[2] and np.isfinite(s[1])
         wa.free(); wb.free()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_spmv_formats_randomised_differential(ctx, oracle, seed):
+    """Seeded random matrices across the format decisions (row lengths around the lane-per-row limit, value pools
+    around 255 / 256 / 257, banded / windowed / scattered columns, with and without a full diagonal, empty rows, 32-
+    and 64-bit row pointers, rectangular): whatever kernel the library picks, y equals the CRS-value kernel's bit for
+    bit and the oracle's within the kernel tolerance."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 6000))
+    n_cols = n + int(rng.integers(0, 2)) * int(rng.integers(0, 500))
+    max_len = int(rng.choice([1, 3, 7, 27, 39, 40, 41, 45]))
+    lens = rng.integers(0, max_len + 1, n)
+    if rng.integers(0, 2):
+        lens[rng.integers(0, n, max(1, n // 10))] = 0
+    lens = np.minimum(lens, n_cols)
+    pool_n = int(rng.choice([1, 2, 17, 255, 256, 257, 400]))
+    pool = np.unique(rng.uniform(-4, 4, pool_n + 8))[:pool_n]
+    style = int(rng.integers(0, 3))  # 0 band around the row, 1 a few far windows, 2 scattered
+    full_diag = bool(rng.integers(0, 2)) and n_cols >= n
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    col = np.empty(rp[-1], dtype=np.int32)
+    val = np.empty(rp[-1])
+    offs = rng.integers(0, max(n_cols - 64, 1), 5)
+    for r in range(n):
+        k0, k1 = rp[r], rp[r + 1]
+        m = k1 - k0
+        if m == 0:
+            continue
+        if style == 0:
+            cand = np.arange(max(0, r - 60), min(n_cols, r + 61))
+        elif style == 1:
+            cand = np.unique(np.concatenate([(o + np.arange(64)) % n_cols for o in offs] + [np.array([min(r, n_cols - 1)])]))
+        else:
+            cand = np.arange(n_cols)
+        c = rng.choice(cand, size=min(m, len(cand)), replace=False)
+        if len(c) < m:
+            c = np.concatenate([c, rng.choice(cand, size=m - len(c))])  # duplicates allowed
+        if full_diag and r not in c:
+            c[0] = r
+        col[k0:k1] = np.sort(c) if rng.integers(0, 2) else c
+        val[k0:k1] = rng.choice(pool, size=m)
+        if full_diag:
+            hit = np.nonzero(col[k0:k1] == r)[0]
+            val[k0 + hit[:1]] = rng.uniform(5, 6)  # a distinct diagonal value per row
+    A = CRS(n, rp, col, val, n_cols=n_cols)
+    x = rng.uniform(-1, 1, n_cols)
+    ctx.set_option("force_rp64", int(rng.integers(0, 2)))
+    try:
+        ys = {}
+        for mode in (0, -1):
+            ctx.set_option("spmv_valdict", mode)
+            dA = ctx.matrix(A)
+            info = dA.spmv_stream_info()
+            dx, dy = ctx.upload(x), ctx.alloc(n)
+            ctx.spmv(dA, dx, dy)
+            ctx.spmv(dA, dx, dy)  # the second call reuses the structures the first one built
+            ys[mode] = dy.to_host()
+            dA.free(); dx.free(); dy.free()
+        assert np.array_equal(ys[0], ys[-1]), (seed, info, n, max_len, pool_n, style, full_diag)
+        yo = oracle.spmv(A, x)
+        assert np.max(np.abs(ys[-1] - yo)) <= KTOL * max(np.abs(A.to_scipy()).dot(np.abs(x)).max(), 1e-300)
+    finally:
+        ctx.set_option("spmv_valdict", -1)
+        ctx.set_option("force_rp64", -1)
