@@ -1218,3 +1218,68 @@ def test_spmv_formats_randomised_differential(ctx, oracle, seed):
     finally:
         ctx.set_option("spmv_valdict", -1)
         ctx.set_option("force_rp64", -1)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_tiled_sweep_random_stencils(ctx, oracle, capfd, monkeypatch, seed):
+    """The device-built tile plan on random stencils: a random grid (extents, unknowns per node), a random subset of
+    the neighbour offsets within distance 2 that precede a row in the natural order (some need skews, some admit none
+    within the search range), random values, as an uploaded matrix with a grid hint.  Forward sweep of the lower and
+    backward sweep of the transposed (upper) pattern: where the plan applies bit-exact against the fma oracle, where it
+    is refused the level kernels' result within their tolerance."""
+    monkeypatch.setenv("BIS_TRSV_TILE_STATS", "1")
+    rng = np.random.default_rng(500 + seed)
+    nx, ny, nz = (int(rng.integers(3, 14)) for _ in range(3))
+    dof = int(rng.choice([1, 1, 2, 3]))
+    reach = int(rng.choice([1, 1, 2]))
+    cand = [(dx, dy, dz, dd) for dz in range(-reach, reach + 1) for dy in range(-reach, reach + 1)
+            for dx in range(-reach, reach + 1) for dd in range(-(dof - 1), dof)
+            if (dz, dy, dx, dd) < (0, 0, 0, 0)]
+    pick = rng.random(len(cand)) < rng.uniform(0.15, 0.7)
+    sten = [c for c, p in zip(cand, pick) if p] or [cand[-1]]
+    n = nx * ny * nz * dof
+    rows = [[] for _ in range(n)]
+    for z in range(nz):
+        for y in range(ny):
+            for x in range(nx):
+                for d in range(dof):
+                    r = ((z * ny + y) * nx + x) * dof + d
+                    for dx, dy, dz, dd in sten:
+                        X, Y, Z, Dd = x + dx, y + dy, z + dz, d + dd
+                        if 0 <= X < nx and 0 <= Y < ny and 0 <= Z < nz and 0 <= Dd < dof:
+                            rows[r].append(((Z * ny + Y) * nx + X) * dof + Dd)
+    for r in range(n):
+        rows[r].sort()
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])])
+    col = np.array([c for cs in rows for c in cs], dtype=np.int32)
+    L = CRS(n, rp, col, rng.uniform(-0.3, 0.3, len(col)))
+    U = L.to_scipy().T.tocsr()
+    U.sort_indices()
+    U = CRS(n, U.indptr, U.indices.astype(np.int32), U.data)
+    D, b = rng.uniform(1, 2, n), rng.uniform(-1, 1, n)
+    want_f, want_b = oracle.sptrsv(L, D, b), oracle.sptrsv(U, D, b, backward=True)
+    dD, db, x = ctx.upload(D), ctx.upload(b), ctx.alloc(n)
+    got, planned = {}, {}
+    try:
+        for mode in (0, -1):
+            ctx.set_option("trsv_tiled", mode)
+            dL, dU = ctx.matrix(L), ctx.matrix(U)
+            dL.set_grid_hint(nx, ny, nz, dof); dU.set_grid_hint(nx, ny, nz, dof)
+            capfd.readouterr()
+            ctx.sptrsv(dL, x, dD, db)
+            f = x.to_host()
+            ctx.bsptrsv(dU, x, dD, db)
+            got[mode] = (f, x.to_host())
+            planned[mode] = capfd.readouterr().err.count("tiled sptrsv plan")
+            dL.free(); dU.free()
+        assert planned[0] == 0 and planned[-1] in (0, 2)
+        scale = max(np.max(np.abs(want_f)), np.max(np.abs(want_b)))
+        for mode in (0, -1):
+            for k, want in enumerate((want_f, want_b)):
+                if planned[mode]:  # the tiled sweep keeps the reference's CRS-order fma chain: bit-exact
+                    assert np.array_equal(got[mode][k], want), (seed, mode, k, nx, ny, nz, dof, sten)
+                else:  # small grids fall to the few-level kernels (products, then sums): kernel tolerance
+                    assert np.max(np.abs(got[mode][k] - want)) <= 1e-12 * scale, (seed, mode, k)
+    finally:
+        ctx.set_option("trsv_tiled", -1)
+    capfd.readouterr()
