@@ -26,6 +26,15 @@
 //     bytes per non-zero; the CRS arrays stay authoritative.  Falls back to the
 //     32-bit columns when a block needs more windows.
 //
+//   * value dictionary (default where it applies): a matrix with at most 256
+//     distinct values -- or whose entries off the diagonal have at most 255 --
+//     streams a 1-byte value code per non-zero against a table in LDS: 3 bytes
+//     per non-zero, bit-identical y.  Two kernels: lane-per-row with the codes
+//     staged through LDS (spmv_rowmajor_vd_kernel, its own packing over 256-row
+//     blocks, 8 windows of 8192 or 32 of 2048 columns) and the consecutive form
+//     on the row-block tables (spmv_rowblock_vd_kernel).  See "Value-dictionary
+//     variant" below and DESIGN.md section 4.
+//
 // Rows longer than the LDS budget fall back to a wave-per-row kernel.
 // An optional fused epilogue accumulates sum_r y[r]*w[r] (the (Ap,p) of
 // cg.hpp:23) into per-wave partials so CG needs no separate dot pass; a third
