@@ -78,6 +78,7 @@ struct bis_options {
     int spmv_packed = -1;  // 16-bit packed column stream: 0 off, 1 select tree, 2 lane permute (-1: default = 1)
     int spmv_valdict = -1; // value dictionary (a matrix with <= 256 distinct values streams 1-byte value codes): 0 off, 1 consecutive form only, 2 lane-per-row form where it applies (-1: default)
     int dist_host_plan = -1; // 1: bis_dist_create plans the halo on the host from the downloaded structure (default: on the device)
+    int grid_autodetect = -1; // bis_mat_create: recognise a stencil on a structured grid from the offsets of a few rows (0: off)
     int trsv_tiled = -1;    // natural-order sweeps: -1 = tiled sweep (bis_trsv_tiled.hip) where its device plan applies (grid hint), 1 = also with the host plan, 2 = host plan only, 0 = level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)

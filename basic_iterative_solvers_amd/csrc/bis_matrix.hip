@@ -11,6 +11,10 @@
 // first non-zero and run past its last one.
 #include "bis_internal.hpp"
 
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 #include <cstdlib>
 
 namespace {
@@ -465,6 +469,59 @@ bis_status bis_mat_row_view(bis_ctx *ctx, const bis_mat *A, int64_t ra, int64_t 
     return BIS_OK;
 }
 
+// Does the host CRS look like a one-unknown-per-node stencil on an nx x ny x nz grid in natural order (x fastest)?  Read
+// off the positive column offsets of a few rows in the middle of the matrix: {1}, a run around nx, runs around the
+// plane size nx*ny.  Only a HINT for the tiled triangular sweep, which verifies the order it derives from it against
+// every entry (bis_trsv_tiled.hip): a wrong guess costs one refused plan, never a wrong result.
+template <class RP>
+static bool guess_grid_hint(int64_t n, const RP *rp, const int32_t *col, int64_t g[4]) {
+    if (n < 4096) return false;
+    int64_t last[3] = {0, 0, 0};
+    int agree = 0;
+    for (int attempt = 0; attempt < 24 && agree < 2; ++attempt) {
+        const int64_t r = (n / 2 + (int64_t)attempt * 37) % n;
+        std::vector<int64_t> pos;
+        for (int64_t k = (int64_t)rp[r]; k < (int64_t)rp[r + 1]; ++k)
+            if (col[k] > r) pos.push_back((int64_t)col[k] - r);
+        std::sort(pos.begin(), pos.end());
+        pos.erase(std::unique(pos.begin(), pos.end()), pos.end());
+        if (pos.empty() || pos[0] != 1) continue;
+        std::vector<std::pair<int64_t, int64_t>> runs; // maximal runs of consecutive offsets
+        for (int64_t o : pos) {
+            if (!runs.empty() && o == runs.back().second + 1) runs.back().second = o;
+            else runs.push_back({o, o});
+        }
+        if (runs[0] != std::make_pair<int64_t, int64_t>(1, 1) || runs.size() < 2) continue;
+        bool ok = true;
+        std::vector<int64_t> centre;
+        for (size_t i = 1; i < runs.size() && ok; ++i) {
+            const int64_t w = runs[i].second - runs[i].first + 1;
+            if (w == 1) centre.push_back(runs[i].first);
+            else if (w == 3) centre.push_back(runs[i].first + 1);
+            else ok = false;
+        }
+        if (!ok) continue;
+        const int64_t nx = centre[0];
+        int64_t plane = 0;
+        if (centre.size() >= 4 && centre[2] - centre[1] == nx && centre[3] - centre[2] == nx) plane = centre[2];
+        else if (centre.size() >= 2) plane = centre[1];
+        int64_t ny, nz;
+        if (plane == 0) {
+            if (n % nx) continue;
+            ny = n / nx; nz = 1;
+        } else {
+            if (plane % nx || n % plane) continue;
+            ny = plane / nx; nz = n / plane;
+        }
+        if (nx < 2 || ny < 2) continue;
+        if (agree && last[0] == nx && last[1] == ny && last[2] == nz) ++agree;
+        else { last[0] = nx; last[1] = ny; last[2] = nz; agree = 1; }
+    }
+    if (agree < 2) return false;
+    g[0] = last[0]; g[1] = last[1]; g[2] = last[2]; g[3] = 1;
+    return true;
+}
+
 extern "C" {
 
 static bis_status mat_create_common(bis_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz,
@@ -526,6 +583,11 @@ static bis_status mat_create_common(bis_ctx *ctx, int64_t n_rows, int64_t n_cols
         ctx->err = "bis_mat_create: non-zeros without rows";
         bis_mat_destroy(ctx, A);
         return BIS_ERR_INVALID;
+    }
+    if (bis_opts().grid_autodetect != 0 && n_rows == n_cols && nnz > 0) {
+        int64_t g[4];
+        const bool hit = src64 ? guess_grid_hint(n_rows, (const int64_t *)row_ptr, col, g) : guess_grid_hint(n_rows, (const int32_t *)row_ptr, col, g);
+        if (hit) for (int i = 0; i < 4; ++i) A->grid[i] = g[i];
     }
     st = bis_mat_finalize(ctx, A);
     if (st != BIS_OK) { bis_mat_destroy(ctx, A); return st; }

@@ -147,7 +147,9 @@ BIS_API bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A,
                                             int *n_dict, int *form);
 /* Structured-grid hint: the rows are the unknowns of an nx x ny x nz grid, x
  * fastest, dof unknowns per node (row = ((z*ny + y)*nx + x)*dof + d) -- e.g.
- * an HPCG-n.mtx read from a file.  The generators set it themselves; strict
+ * an HPCG-n.mtx read from a file.  The generators set it themselves, and
+ * bis_mat_create recognises one-unknown-per-node stencils of 4096 rows or more
+ * from the column offsets of a few rows (option "grid_autodetect" 0: off); strict
  * triangles and ILU(0) factors inherit it.  Only the tiled triangular sweep
  * uses it (tiles that extend in all grid directions); a hint that does not
  * describe the matrix costs speed, never correctness (the tile order is

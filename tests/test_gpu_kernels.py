@@ -811,8 +811,8 @@ def test_tiled_sweep_grid_hint(ctx, oracle, capfd, monkeypatch):
     """bis_mat_set_grid_hint on an uploaded matrix: a true hint gives the tiled sweep (device plan; pairs of x
     neighbours read as two unknowns of one node are a true description too), a hint that does not describe the
     pattern is found out by the plan's own checks (no admissible skew, or the order is not a linear extension) and
-    costs nothing but falling back to the level-scheduled kernels; the sweeps are bit-exact either way, and so is the
-    default without a hint."""
+    costs nothing but falling back to the level-scheduled kernels; without a hint bis_mat_create recognises the grid
+    from the column offsets of a few rows (option grid_autodetect); the sweeps are bit-exact in every case."""
     monkeypatch.setenv("BIS_TRSV_TILE_STATS", "1")
     A = oracle.gen_hpcg(24)
     n = A.n_rows
@@ -821,9 +821,11 @@ def test_tiled_sweep_grid_hint(ctx, oracle, capfd, monkeypatch):
     b = np.random.default_rng(23).uniform(-1, 1, n)
     want_f, want_b = oracle.sptrsv(Ls, D, b), oracle.sptrsv(Us, D, b, backward=True)
     db, x = ctx.upload(b), ctx.alloc(n)
-    for hint, tiled in (((24, 24, 24, 1), True), ((12, 24, 24, 2), True), ((48, 12, 24, 1), False), ((16, 36, 24, 1), None), (None, False)):
-        dA = ctx.matrix(A)
-        if hint:
+    for hint, tiled in (((24, 24, 24, 1), True), ((12, 24, 24, 2), True), ((48, 12, 24, 1), False), ((16, 36, 24, 1), None), (None, True), ("off", False)):
+        ctx.set_option("grid_autodetect", 0 if hint == "off" else -1)
+        dA = ctx.matrix(A)  # no hint given: the grid is recognised from the rows' column offsets (unless switched off)
+        ctx.set_option("grid_autodetect", -1)
+        if hint and hint != "off":
             dA.set_grid_hint(*hint)
         dLs, dUs, dD, _ = ctx.split_strict(dA)
         capfd.readouterr()

@@ -287,3 +287,13 @@ def test_cli_grid_hint_and_trsv_modes(tmp_path, oracle, monkeypatch, solver, pc)
     assert gen == gen_level == plain and n_gen >= 1 and n_gen_dev == n_gen and n_gl == 0
     bad = subprocess.run([BIN, mtx, "-cg", "-grid", "12,13,13"], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "-grid" in bad.stderr
+    # from 4096 rows on bis_mat_create recognises the grid of such a file by itself (column offsets of a few rows)
+    B = oracle.gen_hpcg(16, 17, 18)
+    mtx2 = str(tmp_path / "grid2.mtx")
+    with open(mtx2, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (B.n_rows, B.n_rows, len(B.col)))
+        rows = np.repeat(np.arange(B.n_rows), np.diff(B.row_ptr))
+        np.savetxt(f, np.column_stack([rows + 1, B.col + 1, B.val]), fmt="%d %d %.17g")
+    auto, n_auto, n_auto_dev = run(mtx2, [])
+    lvl, n_lvl, _ = run(mtx2, ["-trsv", "level"])
+    assert len(auto) > 3 and auto == lvl and n_auto >= 1 and n_auto_dev == n_auto and n_lvl == 0
