@@ -496,6 +496,12 @@ class Dist:
         return dict(halo_entries=nh.value, send_entries=ns.value, halo_bytes_per_spmv=8 * (nh.value + ns.value),
                     interior_rows=ni.value, neighbours=nn.value, rccl_ranks_seen=nr.value)
 
+    def spmv_stream_info(self):
+        """(col_bytes, val_bytes, n_dict, form) of the interior rows' SpMV (bis_dist_spmv_stream_info)."""
+        c, v, n, f = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.bis_dist_spmv_stream_info(self.ctx.h, self.h, C.byref(c), C.byref(v), C.byref(n), C.byref(f)))
+        return c.value, v.value, n.value, f.value
+
     def profile_read(self):
         ne, na = C.c_int64(), C.c_int64()
         te, ta = C.c_double(), C.c_double()

@@ -606,6 +606,12 @@ bis_status bis_dist_stats(const bis_dist *d, int64_t *n_halo, int64_t *n_send, i
     return BIS_OK;
 }
 
+bis_status bis_dist_spmv_stream_info(bis_ctx *ctx, const bis_dist *d, int *col_bytes, int *val_bytes, int *n_dict, int *form) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d && d->mid, "bis_dist_spmv_stream_info: null handle");
+    return bis_mat_spmv_stream_info(ctx, d->mid, col_bytes, val_bytes, n_dict, form);
+}
+
 bis_status bis_dist_profile_read(bis_ctx *ctx, bis_dist *d, int64_t *n_exchange, double *exchange_ms,
                                  int64_t *n_allreduce, double *allreduce_ms) {
     BIS_CTX_OK(ctx);

@@ -122,11 +122,15 @@ def run_distributed(args, rank, world, local_rank):
     launches, spmv_ms = ctx.profile_read()
     comm = d.profile_read()
     iters, conv, hist = cg.status(hist_cap=args.warmup + args.steps + 1)
+    col_b, val_b, n_dict, form = d.spmv_stream_info()
+    kernel = ("spmv_rowblock_kernel", "spmv_rowblock_vd_kernel", "spmv_rowmajor_vd_kernel", "spmv_rowmajor_vd_kernel")[form]
     mine = dict(rank=rank, device=local_rank, rows=nl, nnz=nnz_local, setup_s=setup_s, **d.stats(),
                 spmv_ms_per_iter=spmv_ms / max(args.steps, 1),
                 exchange_ms_per_iter=comm["exchange_ms"] / max(args.steps, 1),
                 allreduce_ms_per_iter=comm["allreduce_ms"] / max(args.steps, 1),
-                exchanges=comm["exchanges"], allreduces=comm["allreduces"])
+                exchanges=comm["exchanges"], allreduces=comm["allreduces"],
+                spmv_stream=dict(col_bytes=col_b, val_bytes=val_b, dictionary_values=n_dict, kernel=kernel,
+                                 per_row_diagonal=form == 3))
     per_rank = [None] * world
     td.all_gather_object(per_rank, mine, group=host_group)
     el = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
@@ -161,7 +165,7 @@ def run_distributed(args, rank, world, local_rank):
             "spmv_gflops": 2.0 * nnz / spmv_avg_s / 1e9,
             "residual_r0": r0, "residual_r0_closed_form": r0_exact, "residual_last": float(hist[-1]),
             "transport": transport, "per_rank": per_rank,
-            "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel (interior + boundary launches)",
+            "roofline": {"bound": "hbm", "kernel": kernel + " (interior + boundary launches; rank 0's interior rows)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
                          "algorithmic_bytes_per_launch": spmv_bytes,

@@ -549,6 +549,11 @@ BIS_API bis_status bis_dist_use_rccl(bis_ctx *ctx, bis_dist *d,
 BIS_API bis_status bis_dist_stats(const bis_dist *d, int64_t *n_halo,
                                   int64_t *n_send, int64_t *interior_rows,
                                   int *n_neighbours, int *rccl_ranks);
+/* bis_mat_spmv_stream_info of this rank's interior rows (the launch that
+ * overlaps the halo exchange): which SpMV kernel the partitioned path runs. */
+BIS_API bis_status bis_dist_spmv_stream_info(bis_ctx *ctx, const bis_dist *d,
+                                             int *col_bytes, int *val_bytes,
+                                             int *n_dict, int *form);
 /* While bis_profile_enable is on, every halo exchange (on the communication
  * stream) and every scalar all-reduce (on the compute stream) is bracketed by
  * HIP events; returns counts and summed milliseconds and resets (blocking). */
