@@ -355,6 +355,12 @@ class Mat:
         self.ctx.check(self.ctx.lib.bis_mat_spmv_stream_info(self.ctx.h, self.h, C.byref(c), C.byref(v), C.byref(d), C.byref(f)))
         return c.value, v.value, d.value, f.value
 
+    def spmv_streamed_bytes(self):
+        """Bytes one SpMV launch moves at least with the matrix' current stream format (bis_mat_spmv_streamed_bytes)."""
+        b = C.c_int64()
+        self.ctx.check(self.ctx.lib.bis_mat_spmv_streamed_bytes(self.ctx.h, self.h, C.byref(b)))
+        return b.value
+
     def set_grid_hint(self, nx, ny, nz, dof=1):
         self.ctx.check(self.ctx.lib.bis_mat_set_grid_hint(self.h, _i64(nx), _i64(ny), _i64(nz), C.c_int(dof)))
 

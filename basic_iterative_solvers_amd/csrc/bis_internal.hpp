@@ -84,6 +84,7 @@ struct bis_options {
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
     int trsv_tile_edge = -1; // grid-hinted matrices: tile extents in nodes, e (cubic) or ex | ey << 8 | ez << 16 (default by row length; 0 = interval tiles of the natural order)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
+    int spmv_sellwin = -1; // dictionary SpMV with the block's x window in LDS and sliced-ELL codes (bis_spmv_sell.hip): 0 off (-1: on where the matrix qualifies)
     int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes
 };
 // row_ptr width of a new matrix: int64 when the non-zeros (plus the stream padding) do not fit int32
@@ -143,6 +144,9 @@ struct bis_mat {
     int32_t *rm_seg = nullptr;  // [rm_blocks * 8]
     int64_t rm_base = 0;
     int rm_state = 0, rm_blocks = 0, rm_kind = 1; // rm_kind 1: 8 windows x 8192 columns per block, 3: 32 windows x 2048 columns
+    // x-window + sliced-ELL form of the dictionary kernel (bis_spmv_sell.hip); state as above
+    struct bis_sellwin *sw = nullptr;
+    int sw_state = 0;
     // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
     int32_t *blkf_row = nullptr;
     int64_t *blkf_nnz = nullptr;
@@ -274,6 +278,13 @@ bis_status bis_spmv_build_window(bis_ctx *ctx, bis_mat *A);
 void bis_spmv_drop_packed(bis_mat *A);
 void bis_spmv_drop_valdict(bis_mat *A); // after the values of A changed in place
 bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A, bool consecutive_ok);
+// x-window + sliced-ELL dictionary form (bis_spmv_sell.hip)
+bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A);
+int bis_spmv_sellwin_blocks(const bis_mat *A);
+int64_t bis_spmv_sellwin_bytes(const bis_mat *A);
+bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y, int mode, const double *w,
+                                   double *partials, const int *stop, int remap_arg, int grid);
+void bis_spmv_sellwin_drop(bis_mat *A);
 // try to build the packed-column stream of table t (0 plain, 1 fused); A->pk_state[t] tells the outcome
 bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t);
 // free row-block tables, packed streams and window structures (not the CRS arrays)

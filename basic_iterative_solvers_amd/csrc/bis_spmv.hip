@@ -978,6 +978,7 @@ void bis_spmv_drop_valdict(bis_mat *A) {
     A->vcode = nullptr; A->vdict = nullptr; A->vdiag = nullptr; A->vd_diag = false; A->vd_state = 0; A->vd_n = 0;
     hipFree(A->rm_nnz); hipFree(A->rm_pk); hipFree(A->rm_seg);
     A->rm_nnz = nullptr; A->rm_pk = nullptr; A->rm_seg = nullptr; A->rm_state = 0; A->rm_blocks = 0;
+    bis_spmv_sellwin_drop(A);
 }
 
 // the 256-row blocks of the lane-per-row form and their packed column stream; rm_state tells the outcome
@@ -1195,6 +1196,32 @@ static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArg
     return BIS_OK;
 }
 
+// x-window + sliced-ELL form of the dictionary kernel (bis_spmv_sell.hip) where the matrix qualifies; modes 0 and 1
+static bool sellwin_wanted(const SpmvArgs &a) {
+    return a.vcode && spmv_valdict_mode() >= 2 && bis_opts().spmv_sellwin != 0 && (bis_opts().spmv_variant < 0 || bis_opts().spmv_variant == 20);
+}
+static bis_status launch_sellwin(bis_ctx *ctx, const bis_mat *A, const SpmvArgs &a, const double *x, double *y, int mode,
+                                 const double *w, double *partials, size_t partials_off, int *n_partials, bool *done) {
+    *done = false;
+    if (mode == 2 || !sellwin_wanted(a)) return BIS_OK;
+    if (bis_status st = bis_spmv_sellwin_try(ctx, const_cast<bis_mat *>(A))) return st;
+    const int nbr = bis_spmv_sellwin_blocks(A);
+    if (!nbr) return BIS_OK;
+    if (mode == 1 && partials_off + (size_t)nbr * 4 > ctx->partials_cap) {
+        ctx->err = "bis_spmv: partials buffer too small (internal)";
+        return BIS_ERR_INVALID;
+    }
+    const int remap_arg = remap_arg_for((nbr + 7) & ~7);
+    bis_prof_begin(ctx);
+    bis_status st = bis_spmv_sellwin_launch(ctx, A, x, y, mode, w, mode == 1 ? partials + partials_off : partials, a.stop,
+                                            remap_arg, grid_for_map(nbr, remap_arg));
+    bis_prof_end(ctx);
+    if (st != BIS_OK) return st;
+    if (mode == 1 && n_partials) *n_partials = nbr * 4;
+    *done = true;
+    return BIS_OK;
+}
+
 // lane-per-row form of the dictionary kernel where the matrix qualifies (*done tells); mode 0 / 1 / 2 as in SpmvArgs
 static bis_status launch_rowmajor(bis_ctx *ctx, const bis_mat *A, const SpmvArgs &a, const double *x, double *y, int mode,
                                   const double *w, double *partials, size_t partials_off, int *n_partials, bool *done) {
@@ -1288,6 +1315,11 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     a.stop = w ? ctx->spmv_stop : nullptr;
     {
         bool done = false;
+        if (bis_status st = launch_sellwin(ctx, A, a, x, y, w ? 1 : 0, w, ctx->partials, partials_off, n_partials, &done)) return st;
+        if (done) return BIS_OK;
+    }
+    {
+        bool done = false;
         if (bis_status st = launch_rowmajor(ctx, A, a, x, y, w ? 1 : 0, w, ctx->partials, partials_off, n_partials, &done)) return st;
         if (done) return BIS_OK;
     }
@@ -1346,7 +1378,11 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
     if (A->n_rows > 0 && sizeof(double) * (size_t)lds_doubles <= 64 * 1024 && !(A->win_ok && spmv_window_mode()))
         if (bis_status st = ensure_packed(ctx, A, 0, &a)) return st;
     int f = 0;
-    if (a.vcode && spmv_valdict_mode() >= 2 && (bis_opts().spmv_variant < 0 || bis_opts().spmv_variant == 20)) {
+    if (sellwin_wanted(a)) {
+        if (bis_status st = bis_spmv_sellwin_try(ctx, const_cast<bis_mat *>(A))) return st;
+        if (bis_spmv_sellwin_blocks(A)) f = A->vd_diag ? 5 : 4;
+    }
+    if (!f && a.vcode && spmv_valdict_mode() >= 2 && (bis_opts().spmv_variant < 0 || bis_opts().spmv_variant == 20)) {
         if (bis_status st = spmv_try_rowmajor(ctx, const_cast<bis_mat *>(A))) return st;
         if (A->rm_state == 1) f = A->vd_diag ? 3 : 2;
     }
@@ -1355,6 +1391,25 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
     if (val_bytes) *val_bytes = f ? 1 : 8;
     if (n_dict) *n_dict = f ? A->vd_n : 0;
     if (form) *form = f;
+    return BIS_OK;
+}
+
+bis_status bis_mat_spmv_streamed_bytes(bis_ctx *ctx, const bis_mat *A, int64_t *bytes) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, A && bytes, "bis_mat_spmv_streamed_bytes: bad arguments");
+    int col_b = 4, val_b = 8, n_dict = 0, form = 0;
+    if (bis_status st = bis_mat_spmv_stream_info(ctx, A, &col_b, &val_b, &n_dict, &form)) return st;
+    const int64_t rp = A->rp64 ? 8 : 4;
+    int64_t b = 8 * A->n_cols + 8 * A->n_rows; // x once, y once
+    if (form >= 4) {
+        b += bis_spmv_sellwin_bytes(A);
+    } else if (form >= 2) {
+        b += 3 * A->nnz + rp * (A->n_rows + 1) + (int64_t)A->rm_blocks * (A->rm_kind == 3 ? 128 : 32) + 2048;
+    } else {
+        b += (int64_t)(col_b + val_b) * A->nnz + rp * (A->n_rows + 1) + (int64_t)A->n_blocks * (12 + (col_b == 2 ? 32 : 0)) + (form == 1 ? 2048 : 0);
+    }
+    if (form == 3 || form == 5) b += 8 * A->n_rows; // the per-row diagonal values
+    *bytes = b;
     return BIS_OK;
 }
 

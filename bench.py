@@ -100,22 +100,66 @@ def measured_stream(ctx, N):
     return out
 
 
+KERNEL_OF_FORM = ("spmv_rowblock_kernel", "spmv_rowblock_vd_kernel", "spmv_rowmajor_vd_kernel", "spmv_rowmajor_vd_kernel",
+                  "spmv_sellwin_kernel", "spmv_sellwin_kernel")
+
+
 def stream_format(A):
-    """What the SpMV streams per non-zero for this matrix (bis_mat_spmv_stream_info)."""
+    """What the SpMV streams for this matrix (bis_mat_spmv_stream_info / bis_mat_spmv_streamed_bytes)."""
     col_b, val_b, n_dict, form = A.spmv_stream_info()
-    return {"col_bytes": col_b, "val_bytes": val_b, "dictionary_values": n_dict,
-            "kernel": ("spmv_rowblock_kernel", "spmv_rowblock_vd_kernel", "spmv_rowmajor_vd_kernel")[form],
-            "streamed_bytes_per_nnz": col_b + val_b}
+    return {"col_bytes": col_b, "val_bytes": val_b, "dictionary_values": n_dict, "form": form,
+            "kernel": KERNEL_OF_FORM[form], "streamed_bytes_per_nnz": col_b + val_b,
+            "streamed_bytes_per_launch": A.spmv_streamed_bytes()}
 
 
-def crs_value_leg(ctx, A, b, x, D, steps, warmup):
-    """The same CG on the same arrays with the value dictionary switched off (the kernel streams the 8-byte CRS
-    values): the comparable of round 1's number, measured after the timed region."""
-    ctx.set_option("spmv_valdict", 0)
+def load_traffic(path, size, kernel):
+    """Per-launch HBM bytes of `kernel` from the rocprofv3 PMC passes of this command (tools/pmc_traffic.py writes
+    the file from separate FETCH_SIZE / WRITE_SIZE runs); None when no pass covers this kernel at this size."""
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None
+    if tj.get("size") != size:
+        return None
+    if "kernels" in tj:
+        k = tj["kernels"].get(kernel)
+        return k.get("hbm_bytes_per_launch") if k else None
+    return tj.get("hbm_bytes_per_launch") if tj.get("kernel", "spmv_rowblock_kernel") == kernel else None
+
+
+def spmv_roofline(A, avg_s, launches, traffic_path, size):
+    """The roofline record of the SpMV launches of one leg.  `achieved` / `frac` price the bytes the kernel MOVES:
+    the PMC-measured HBM traffic per launch where a pass exists for this kernel, else the bytes of the stream format
+    it reads (its arrays once, x once, y once) -- a fraction of the HBM ceiling, <= 1 by construction.  The CRS byte
+    count of the reference's loop (12 nnz + 20 N) over the same time is kept beside it as
+    crs_equivalent_GBs: for a kernel that streams a lossless re-encoding it is a speed-up figure, not a bandwidth."""
+    fmt = stream_format(A)
+    N, nnz = A.n_rows, A.nnz
+    crs_bytes = 12 * nnz + (24 if A.rp_width == 8 else 20) * N
+    traffic = load_traffic(traffic_path, size, fmt["kernel"])
+    moved = traffic if traffic else fmt["streamed_bytes_per_launch"]
+    achieved = moved / avg_s / 1e9
+    return {"bound": "hbm", "kernel": fmt["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "priced_on": "PMC HBM traffic per launch" if traffic else "bytes of the stream format (no PMC pass for this kernel/size)",
+            "avg_launch_ms": avg_s * 1e3, "launches": launches,
+            "streamed_bytes_per_launch": fmt["streamed_bytes_per_launch"],
+            "streamed_GBs": fmt["streamed_bytes_per_launch"] / avg_s / 1e9,
+            "streamed_frac_of_peak": fmt["streamed_bytes_per_launch"] / avg_s / 1e9 / HBM_PEAK_GBS,
+            "crs_algorithmic_bytes_per_launch": crs_bytes, "crs_equivalent_GBs": crs_bytes / avg_s / 1e9,
+            "crs_equivalent_frac_of_peak": crs_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+            "spmv_gflops": 2.0 * nnz / avg_s / 1e9, "spmv_stream": fmt}
+
+
+def cg_leg(ctx, A, b, x, D, steps, warmup, traffic_path, size, valdict=None):
+    """`steps` timed CG iterations after `warmup` on (A, b, x = 0.1); valdict=0: with the value dictionary off (the
+    kernel streams the 8-byte CRS values: SURVEY 8d's 'CRS SpMV')."""
+    if valdict is not None:
+        ctx.set_option("spmv_valdict", valdict)
     try:
         ctx.init_vector(x, 0.1)
         cg = ctx.cg(A, b, x, D)
-        cg.init(0.0)
+        r0 = cg.init(0.0)
         cg.iterate(warmup)
         ctx.sync()
         ctx.profile(True)
@@ -128,56 +172,64 @@ def crs_value_leg(ctx, A, b, x, D, steps, warmup):
         iters, conv, hist = cg.status(hist_cap=warmup + steps + 1)
         assert iters == warmup + steps
         cg.free()
+        avg_s = spmv_ms * 1e-3 / max(launches, 1)
+        roof = spmv_roofline(A, avg_s, launches, traffic_path, size)
     finally:
-        ctx.set_option("spmv_valdict", -1)
-    N = A.n_rows
-    avg_s = spmv_ms * 1e-3 / max(launches, 1)
-    spmv_bytes = 12 * A.nnz + 20 * N
-    return {"note": "option spmv_valdict=0: 8-byte CRS values streamed (2-byte column codes as before)",
-            "steps": steps, "warmup": warmup, "cg_iterations_per_s": steps / secs, "ms_per_step": 1e3 * secs / steps,
-            "spmv_avg_launch_ms": avg_s * 1e3, "spmv_GBs": spmv_bytes / avg_s / 1e9,
-            "spmv_frac_of_peak": spmv_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "spmv_gflops": 2.0 * A.nnz / avg_s / 1e9,
-            "residual_history": [float(h) for h in hist]}
+        if valdict is not None:
+            ctx.set_option("spmv_valdict", -1)
+    return {"steps": steps, "warmup": warmup, "cg_iterations_per_s": steps / secs, "ms_per_step": 1e3 * secs / steps,
+            "spmv_avg_launch_ms": avg_s * 1e3, "spmv_frac_of_peak": roof["frac"], "roofline": roof,
+            "residual_r0": r0, "residual_history": [float(h) for h in hist]}
 
 
-def target_512(ctx, steps=10, warmup=3):
-    """North-star target size: CG on HPCG 512^3 (3.6e9 nnz, int64 row pointers), same fused schedule;
-    the reference's int CRS cannot hold this matrix, so there is no CPU leg (tests/test_gpu_kernels.py
-    gates it through closed forms and the fused-vs-unfused history)."""
+def target_512(ctx, traffic_path, steps=10, warmup=3):
+    """North-star target size: CG on HPCG 512^3 (3.6e9 nnz, int64 row pointers), same fused schedule, first with the
+    default stream format, then (`crs_value_stream`) with the 8-byte CRS values streamed -- the literal 'CRS SpMV inside
+    the CG loop on 512^3'.  The reference's int CRS cannot hold this matrix, so there is no CPU leg
+    (tests/test_gpu_kernels.py gates it through closed forms and the fused-vs-unfused history)."""
     n1 = 512
     N = n1 ** 3
     A = ctx.gen_hpcg(n1)
     b, x = ctx.alloc(N), ctx.alloc(N)
     ctx.init_vector(b, 1.0)
-    ctx.init_vector(x, 0.1)
-    cg = ctx.cg(A, b, x)
-    r0 = cg.init(0.0)
-    cg.iterate(warmup)
-    ctx.sync()
-    ctx.profile(True)
-    t0 = time.perf_counter()
-    cg.iterate(steps)
-    ctx.sync()
-    secs = time.perf_counter() - t0
-    ctx.profile(False)
-    launches, spmv_ms = ctx.profile_read()
-    iters, conv, hist = cg.status(hist_cap=warmup + steps + 1)
-    assert iters == warmup + steps
-    spmv_bytes = 12 * A.nnz + 24 * N  # + 4 N for the int64 row pointers
-    avg_s = spmv_ms * 1e-3 / max(launches, 1)
     rec = {"workload": "HPCG 512^3 27-point, -cg, b=1 x0=0.1, fused device schedule, int64 row_ptr",
-           "rows": N, "nnz": A.nnz, "rp_width": A.rp_width, "steps": steps, "warmup": warmup,
-           "cg_iterations_per_s": steps / secs, "ms_per_step": 1e3 * secs / steps,
-           "spmv_avg_launch_ms": avg_s * 1e3, "spmv_launches": launches,
-           "spmv_algorithmic_bytes": spmv_bytes, "spmv_GBs": spmv_bytes / avg_s / 1e9,
-           "spmv_frac_of_peak": spmv_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
-           "spmv_gflops": 2.0 * A.nnz / avg_s / 1e9, "residual_r0": r0, "residual_last": float(hist[-1]),
-           "spmv_stream": stream_format(A)}
-    cg.free(); A.free(); b.free(); x.free()
+           "rows": N, "nnz": A.nnz, "rp_width": A.rp_width}
+    leg = cg_leg(ctx, A, b, x, None, steps, warmup, traffic_path, n1)
+    h1 = leg.pop("residual_history")
+    rec.update(leg)
+    rec["residual_last"] = h1[-1]
+    crs = cg_leg(ctx, A, b, x, None, steps, warmup, traffic_path, n1, valdict=0)
+    h2 = crs.pop("residual_history")
+    crs["note"] = "option spmv_valdict=0: 8-byte CRS values streamed (2-byte column codes)"
+    crs["history_max_dev_over_r0_vs_default_leg"] = max(abs(a - c) for a, c in zip(h1, h2)) / h1[0]
+    rec["crs_value_stream"] = crs
+    A.free(); b.free(); x.free()
     return rec
 
 
-def cpu_baseline(size, precond, iters):
+def unstructured_spmv(ctx, launches=20):
+    """BASELINE config 5's SpMV: the CRS row-block kernel on the unstructured stand-in (fem:80,80,81, rows of 18-81
+    entries, more than 256 distinct values: no dictionary), HIP-event timed."""
+    A = ctx.gen_fem(80, 80, 81)
+    N = A.n_rows
+    import numpy as np
+    x, y = ctx.upload(np.random.default_rng(12345).uniform(-1, 1, N)), ctx.alloc(N)
+    for _ in range(3):
+        ctx.spmv(A, x, y)
+    ctx.sync()
+    ctx.profile(True)
+    for _ in range(launches):
+        ctx.spmv(A, x, y)
+    ctx.sync()
+    ctx.profile(False)
+    n, ms = ctx.profile_read()
+    rec = {"workload": "fem:80,80,81 (stand-in for Flan_1565), y = A x", "rows": N, "nnz": A.nnz,
+           "roofline": spmv_roofline(A, ms * 1e-3 / max(n, 1), n, os.path.join(ROOT, "profiles", "spmv_traffic_fem.json"), 80)}
+    A.free(); x.free(); y.free()
+    return rec
+
+
+def cpu_baseline(size, precond, iters, threads=None, seconds=15.0):
     """The reference's CG on the host cores of this box.
 
     kind "reference": oracle/_ref (the reference's own ConjugateGradientSolver,
@@ -188,7 +240,8 @@ def cpu_baseline(size, precond, iters):
     import numpy as np
 
     from oracle import pyoracle
-    threads = int(os.environ.get("BIS_CPU_THREADS", "16"))  # the box's CPU share for one GPU
+    if threads is None:
+        threads = int(os.environ.get("BIS_CPU_THREADS", "16"))  # the box's CPU share for one GPU
     pyoracle.set_omp_threads(threads)
     orc = pyoracle.Oracle()
     t0 = time.time()
@@ -197,7 +250,7 @@ def cpu_baseline(size, precond, iters):
     D = np.full(A.n_rows, 26.0) if precond == "j" else None
     _, s1 = orc.cg_run(A, 1, D)
     if iters <= 0:  # size the sample for ~15 s of CPU work
-        iters = int(max(3, min(400, 15.0 / max(s1, 1e-3))))
+        iters = int(max(3, min(400, seconds / max(s1, 1e-3))))
     if pyoracle.Ref.available() and A.nnz < 2 ** 31 - 1 and os.environ.get("BIS_CPU_KIND") != "port":
         ref = pyoracle.Ref()
         r = ref.solve(A, "cg", "j" if precond == "j" else "none", max_iters=iters, tol=1e-300)
@@ -206,8 +259,9 @@ def cpu_baseline(size, precond, iters):
         return dict(value=n_it / secs, unit="CG iterations/s", cores=threads, kind="reference",
                     topology=host_topology(), omp_proc_bind=os.environ.get("OMP_PROC_BIND"),
                     omp_places=os.environ.get("OMP_PLACES"),
+                    build=pyoracle.ref_build_info(),
                     sample=f"HPCG {size}^3 ({A.nnz} nnz), {n_it} CG iterations of the reference's own "
-                           f"ConjugateGradientSolver (oracle/_ref, g++ -O3 -march=native -fopenmp, "
+                           f"ConjugateGradientSolver (oracle/_ref, g++ {pyoracle.ref_build_info().get('flags', '?')}, "
                            f"{threads} OpenMP threads), iterate+sample time from its timer tree; "
                            f"SpMV share {r['spmv_s'] / secs:.2f}",
                     ms_per_step=1e3 * secs / n_it), r["hist"]
@@ -285,21 +339,14 @@ def main():
     secs = t1 - t0
     its = args.steps / secs
 
-    spmv_bytes = 12 * nnz + 20 * N
     spmv_avg_s = spmv_ms * 1e-3 / max(launches, 1)
-    achieved = spmv_bytes / spmv_avg_s / 1e9
-    traffic = None
-    if os.path.exists(args.traffic_json):
-        try:
-            tj = json.load(open(args.traffic_json))
-            if tj.get("size") == n1 and tj.get("kernel", "spmv_rowblock_kernel") == stream_format(A)["kernel"]:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    roof = spmv_roofline(A, spmv_avg_s, launches, args.traffic_json, n1)
     stream = measured_stream(ctx, N)
-    fmt = stream_format(A)
-    streamed_bytes = (fmt["col_bytes"] + fmt["val_bytes"]) * nnz + 20 * N
-    fused_bytes = 12 * nnz + (100 if args.precond == "j" else 84) * N  # SpMV 20 N, pass B 24 N (+16 N Jacobi), pass C 40 N
+    # the streaming ceiling measured on this box: the library's own triad over N-vectors
+    roof["measured_stream_GBs"] = stream["triad"]
+    roof["measured_copy_GBs"] = stream["copy"]
+    roof["frac_of_measured"] = roof["achieved"] / stream["triad"]
+    vec_bytes = (80 if args.precond == "j" else 64) * N  # pass B 24 N (+16 N Jacobi), pass C 40 N
     out = {
         "metric": "CG iterations/sec + SpMV GFLOP/s (% HBM roofline), HPCG 256^3 at 1/2/4/8 GPUs",
         "value": its, "unit": "CG iterations/s", "n_gpus": 1, "steps": args.steps,
@@ -311,46 +358,57 @@ def main():
                                ", b=1 x0=0.1, fused device schedule", "rows": N, "nnz": nnz,
                    "partition": "1 GPU"},
         "spmv_gflops": 2.0 * nnz / spmv_avg_s / 1e9,
-        "cg_effective_GBs": fused_bytes * its / 1e9,
+        # bytes the iteration moves (the SpMV's stream format + the two vector passes) per second ...
+        "cg_effective_GBs": (roof["streamed_bytes_per_launch"] + vec_bytes) * its / 1e9,
+        # ... and what the reference's arrays would need for the same iterations (12 nnz + 20 N + the vector passes)
+        "cg_crs_equivalent_GBs": (12 * nnz + 20 * N + vec_bytes) * its / 1e9,
         "residual_r0": r0, "residual_last": float(hist[-1]),
-        "roofline": {"bound": "hbm", "kernel": fmt["kernel"], "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": spmv_bytes,
-                     "avg_launch_ms": spmv_avg_s * 1e3, "launches": launches,
-                     # the streaming ceiling measured on this box: the library's
-                     # own triad over N-vectors; frac_of_measured prices the SpMV against it
-                     "measured_stream_GBs": stream["triad"], "measured_copy_GBs": stream["copy"],
-                     "frac_of_measured": achieved / stream["triad"],
-                     # what the kernel streams: lossless re-encodings of the CRS arrays (16-bit column codes; 1-byte value
-                     # codes against a dictionary when the matrix has <= 256 distinct values) -- `achieved` above is priced
-                     # on the CRS byte count and can exceed the peak; this is the HBM rate of the bytes moved
-                     "spmv_stream": fmt, "streamed_bytes_per_launch": streamed_bytes,
-                     "streamed_GBs": streamed_bytes / spmv_avg_s / 1e9,
-                     "streamed_frac_of_peak": streamed_bytes / spmv_avg_s / 1e9 / HBM_PEAK_GBS},
+        "roofline": roof,
     }
-    if not args.no_cpu_baseline:
-        cb, cpu_hist = cpu_baseline(n1, args.precond, args.cpu_iters)
-        out["cpu_baseline"] = cb
-        # parity of the timed run against the CPU path on the same input
-        m = min(len(cpu_hist), len(hist))
-        import numpy as np
-        out["parity_max_dr_over_r0"] = float(np.max(np.abs(cpu_hist[:m] - hist[:m])) / cpu_hist[0])
-    if tuned:
-        out["placement_tuning"] = tuned
     cg.free()
-    if fmt["val_bytes"] == 1:
-        import numpy as np
-        leg = crs_value_leg(ctx, A, b, x, D, min(args.steps, 50), min(args.warmup, 5))
+    import numpy as np
+    if roof["spmv_stream"]["val_bytes"] == 1:
+        # SURVEY 8d's "CRS SpMV": the same loop on the same arrays with the 8-byte CRS values streamed
+        leg = cg_leg(ctx, A, b, x, D, min(args.steps, 50), min(args.warmup, 5), args.traffic_json, n1, valdict=0)
         h2 = np.array(leg.pop("residual_history"))
         m2 = min(len(h2), len(hist))
         # same y bit for bit; the fused (Ap, p) is summed over different row blocks, a different fixed order
         leg["history_max_dev_over_r0_vs_timed_run"] = float(np.max(np.abs(h2[:m2] - np.array(hist[:m2]))) / h2[0])
+        leg["note"] = "option spmv_valdict=0: 8-byte CRS values streamed (2-byte column codes as before)"
         out["crs_value_stream"] = leg
+    if not args.no_cpu_baseline:
+        cb, cpu_hist = cpu_baseline(n1, args.precond, args.cpu_iters)
+        out["cpu_baseline"] = cb
+        # parity against the CPU path on the same input over the CPU leg's WHOLE history: a fresh GPU run of as many
+        # iterations as the reference made (the timed run above covers only warmup + steps of them)
+        n_cmp = len(cpu_hist) - 1
+        ctx.init_vector(x, 0.1)
+        cgp = ctx.cg(A, b, x, D)
+        cgp.init(0.0)
+        cgp.iterate(n_cmp)
+        _, _, gh = cgp.status(hist_cap=n_cmp + 1)
+        cgp.free()
+        gh = np.array(gh)
+        m = min(len(cpu_hist), len(gh))
+        out["parity_max_dr_over_r0"] = float(np.max(np.abs(cpu_hist[:m] - gh[:m])) / cpu_hist[0])
+        out["parity_samples"] = int(m)
+        phys = (cb.get("topology") or {}).get("physical_cores") or 0
+        socks = (cb.get("topology") or {}).get("sockets") or 1
+        per_socket = phys // max(socks, 1)
+        if per_socket > cb["cores"] and os.environ.get("BIS_CPU_SOCKET_LEG", "1") != "0":
+            # a second sample on one full socket (fewer iterations), beside the per-GPU share of the host
+            cb2, _ = cpu_baseline(n1, args.precond, 0, threads=per_socket, seconds=5.0)
+            out["cpu_baseline_socket"] = cb2
+    if tuned:
+        out["placement_tuning"] = tuned
     A.free(); b.free(); x.free()
+    if D is not None:
+        D.free()
     if n1 == 256 and not args.no_target_512:
         info = ctx.device_info()
         if info["hbm_bytes"] >= 200e9:
-            out["target_512"] = target_512(ctx)
+            out["target_512"] = target_512(ctx, args.traffic_json)
+            out["config5_spmv"] = unstructured_spmv(ctx)
     print(json.dumps(out), flush=True)
     ctx.close()
 

@@ -138,13 +138,25 @@ BIS_API int bis_mat_rp_width(const bis_mat *A);
  * LDS (rows of at most 40 entries, at most 8 column windows per 256 rows), 3 =
  * the same with the diagonal entries' values in a per-row array beside the
  * dictionary (matrices whose off-diagonal values are few but whose diagonal is
- * not, e.g. the Anderson model: +8 bytes per row).
+ * not, e.g. the Anderson model: +8 bytes per row), 4 / 5 = forms 2 / 3 with the
+ * block's x entries copied into an LDS window by coalesced loads and the codes
+ * stored per 64-row slice in lane order (sliced ELL, 12 bytes per 4 non-zeros
+ * and lane, short rows padded with an arithmetically neutral entry; option
+ * "spmv_sellwin" 0 switches it off).
  * All are lossless re-encodings of the CRS arrays, which stay authoritative:
  * same products, same summation order, bit-identical y.  Option
  * "spmv_valdict" 0 switches the dictionary off, 1 allows form 1 only. */
 BIS_API bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A,
                                             int *col_bytes, int *val_bytes,
                                             int *n_dict, int *form);
+/* Bytes one y = A x launch moves at least with the stream format the matrix
+ * currently has (bis_mat_spmv_stream_info): the format's own arrays once -- for
+ * forms 4 / 5 including the padding of the sliced-ELL stream --, x once
+ * (8 n_cols) and y once (8 n_rows).  The denominator-free part of a roofline
+ * figure for the kernel that actually runs; the CRS figure of the reference's
+ * loop (kernels.hpp:22-42) is 12 nnz + 20 n_rows. */
+BIS_API bis_status bis_mat_spmv_streamed_bytes(bis_ctx *ctx, const bis_mat *A,
+                                               int64_t *bytes);
 /* Structured-grid hint: the rows are the unknowns of an nx x ny x nz grid, x
  * fastest, dof unknowns per node (row = ((z*ny + y)*nx + x)*dof + d) -- e.g.
  * an HPCG-n.mtx read from a file.  The generators set it themselves, and

@@ -27,6 +27,15 @@ def set_omp_threads(n):
     C.CDLL("libgomp.so.1").omp_set_num_threads(C.c_int(int(n)))
 
 
+def ref_build_info():
+    """How and where oracle/_ref was compiled (written by oracle/Makefile next to the libraries)."""
+    import json
+    try:
+        return json.load(open(os.path.join(HERE, "_ref", "build_info.json")))
+    except Exception:
+        return {}
+
+
 def build(ref=True):
     """Compile the oracle (and, when /root/reference exists, oracle/_ref)."""
     subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])

@@ -957,9 +957,18 @@ def _few_values_matrix(rng, n, n_values, empty_head=0):
     return CRS(n, rp, col, val)
 
 
+@pytest.fixture
+def no_sellwin(ctx):
+    """The gather forms of the dictionary kernel (1-3) on their own: the x-window / sliced-ELL form (4-5,
+    bis_spmv_sell.hip), which takes precedence where a matrix qualifies, is switched off for the test."""
+    ctx.set_option("spmv_sellwin", 0)
+    yield
+    ctx.set_option("spmv_sellwin", -1)
+
+
 @pytest.mark.parametrize("rp64", [0, 1])
 @pytest.mark.parametrize("form", [1, 2])
-def test_spmv_value_dictionary(ctx, oracle, form, rp64):
+def test_spmv_value_dictionary(ctx, oracle, form, rp64, no_sellwin):
     """Matrices with at most 256 distinct values (compared bit for bit) stream 1-byte value codes against a
     dictionary held in LDS (bis_mat_spmv_stream_info): a lossless re-encoding -- y is BIT-IDENTICAL to the kernel that
     streams the CRS values (same products, same summation order) and within the kernel tolerance of the oracle's
@@ -1025,7 +1034,7 @@ def test_spmv_value_dictionary(ctx, oracle, form, rp64):
 
 
 @pytest.mark.parametrize("form", [1, 2])
-def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form):
+def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form, no_sellwin):
     """The dictionary kernel's other two epilogues: the fused (Ap, p) of the CG schedule (bis_cg.hip) and the
     triangular-sweep step on a colour block of a multi-coloured matrix.  The sweeps are bit-identical to the ones
     computed from the streamed CRS values; so is the CG history with form 1 (same row blocks, same partial sums of
@@ -1069,7 +1078,7 @@ def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form):
         ctx.set_option("spmv_valdict", -1)
 
 
-def test_value_dictionary_kernel_selection_and_shapes(ctx, oracle):
+def test_value_dictionary_kernel_selection_and_shapes(ctx, oracle, no_sellwin):
     """Which dictionary kernel a matrix gets (bis_mat_spmv_stream_info) and that every choice computes the same y as
     the CRS-value kernel, bit for bit: rows longer than the lane-per-row form's 40 entries -> consecutive form;
     rectangular matrices (more columns than rows: a rank's [owned | halo] numbering) in both encodings; row counts
@@ -1129,6 +1138,141 @@ def test_value_dictionary_kernel_selection_and_shapes(ctx, oracle):
             assert np.max(np.abs(ys[-1] - yo)) <= KTOL * max(np.abs(A.to_scipy()).dot(np.abs(x)).max(), 1e-300), name
     finally:
         ctx.set_option("spmv_valdict", -1)
+
+
+def _banded_few_values(rng, n, n_values, offsets, max_len, ragged=4, empty_every=53, n_cols=None, diag_random=False, huge=True):
+    """Rows of max_len - ragged .. max_len entries at columns r + (an offset of `offsets`), unsorted, duplicates
+    allowed, some empty rows; values drawn from n_values bit patterns (with -0.0, a denormal, huge values)."""
+    n_cols = n_cols or n
+    lens = rng.integers(max(max_len - ragged, 0), max_len + 1, n)
+    if empty_every:
+        lens[::empty_every] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    rows = np.repeat(np.arange(n), lens)
+    col = np.clip(rows + rng.choice(offsets, rp[-1]), 0, n_cols - 1).astype(np.int32)
+    special = np.array([-0.0, 0.0, 5e-324, -1.0, 26.0, 1.7976931348623157e308, -1.7976931348623157e308, 1.0 + 2.0 ** -52])
+    if not huge:
+        special = special[:5]
+    pool = np.concatenate([special, rng.uniform(-3, 3, max(n_values - len(special), 0))])[:n_values]
+    val = pool[rng.integers(0, n_values, rp[-1])]
+    val[:n_values] = pool
+    if diag_random:  # exactly one diagonal entry per non-empty row, with a value of its own
+        for r in range(n):
+            k0, k1 = rp[r], rp[r + 1]
+            if k1 > k0:
+                hit = col[k0:k1] == r
+                col[k0:k1][hit] = min(r + 1, n_cols - 1) if r + 1 < n_cols else r - 1
+                col[k0] = r
+                val[k0] = rng.uniform(5, 6)
+    return CRS(n, rp, col, val, n_cols=n_cols)
+
+
+@pytest.mark.parametrize("rp64", [0, 1])
+def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64):
+    """Forms 4 / 5 of the dictionary SpMV (bis_spmv_sell.hip): the block's x entries in an LDS window, the codes per
+    64-row slice in lane order with neutral padding.  y is BIT-IDENTICAL to the kernel that streams the CRS values and
+    within the kernel tolerance of the oracle (kernels.hpp:22-42): stencils, banded matrices with several column runs,
+    ragged and empty rows, -0.0 / denormal / huge values and -0.0 row sums (the padding must not turn them into +0.0),
+    dictionaries of <= 32 and of up to 255 values, the per-row diagonal form, odd sizes (a window granule that reaches
+    past the last column), an x that is only 8-byte aligned, 64-bit row pointers; matrices that do not qualify (256
+    values: no free code for the padding; scattered columns; mostly-padding rows) keep the gather forms."""
+    rng = np.random.default_rng(90 + rp64)
+    ctx.set_option("force_rp64", rp64)
+    offs_band = np.arange(-40, 41)
+    offs_runs = np.concatenate([np.arange(-3, 4), np.arange(-3, 4) + 700, np.arange(-3, 4) - 700, np.arange(-3, 4) + 5000, np.arange(-3, 4) - 5000])
+    neg0 = CRS(300, np.arange(0, 301 * 3, 3), np.repeat(np.arange(300), 3).astype(np.int32), np.tile([-0.0, 0.0, -0.0], 300))
+    neg0.val[::3] = -1.0  # rows: -1*x + 0*x + -0*x
+    try:
+        cases = [("hpcg 12x10x9", oracle.gen_hpcg(12, 10, 9), 4), ("hpcg 20", oracle.gen_hpcg(20), 4),
+                 ("anderson W=0", oracle.gen_anderson(9, W=0.0, shift=7.0), 4),
+                 ("anderson W=5", oracle.gen_anderson(9, W=5.0, shift=3.0), 5),
+                 ("anderson 12 W=2", oracle.gen_anderson(12, t=0.5, W=2.0), 5),
+                 ("band, 20 values", _banded_few_values(rng, 9001, 20, offs_band, 27), 4),
+                 ("band, 33 values", _banded_few_values(rng, 5000, 33, offs_band, 12), 4),
+                 ("band, 255 values", _banded_few_values(rng, 7000, 255, offs_band, 31, empty_every=0), 4),
+                 ("band, 256 values", _banded_few_values(rng, 7000, 256, offs_band, 31, empty_every=0), 2),
+                 ("five runs", _banded_few_values(rng, 20011, 9, offs_runs, 18, huge=False), 4),
+                 ("five runs, random diagonal", _banded_few_values(rng, 12000, 9, offs_runs, 18, diag_random=True), None),
+                 ("band, 40 values, random diagonal", _banded_few_values(rng, 3000, 40, offs_band, 10, diag_random=True), None),
+                 ("rectangular", _banded_few_values(rng, 3000, 5, np.arange(0, 300), 9, n_cols=3300, huge=False), 4),
+                 ("long rows", _banded_few_values(rng, 2000, 6, np.arange(-100, 101), 70, huge=False), 4),
+                 ("mostly padding", _banded_few_values(rng, 40000, 6, offs_band, 30, ragged=30), 2),
+                 ("scattered", _few_values_matrix(rng, 9000, 12), None),
+                 ("-0.0 sums", neg0, 4), ("one row", CRS(1, [0, 2], [0, 0], [2.0, 3.0]), 4)]
+        for name, A, want in cases:
+            x = rng.uniform(-1, 1, A.n_cols)
+            if name == "-0.0 sums":
+                x[:] = 0.0
+                x[::2] = -0.0
+            ys = {}
+            for mode in (0, -1):
+                ctx.set_option("spmv_valdict", mode)
+                dA = ctx.matrix(A)
+                info = dA.spmv_stream_info()
+                if mode == -1 and want is not None:
+                    assert info[3] == want, (name, info)
+                if mode == -1 and "random diagonal" in name:
+                    assert info[3] in (5, 3, 0), (name, info)
+                dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
+                ctx.spmv(dA, dx, dy)
+                ys[mode] = dy.to_host()
+                if mode == -1:  # an x that is only 8-byte aligned: the window is filled through registers
+                    dx1 = ctx.upload(np.concatenate([[7.0], x]))
+                    ctx.init_vector(dy, 3.0)
+                    ctx.spmv(dA, dx1.offset(1), dy)
+                    ys["unaligned"] = dy.to_host()
+                    dx1.free()
+                dA.free(); dx.free(); dy.free()
+            assert np.array_equal(ys[0].view(np.uint64), ys[-1].view(np.uint64)) or \
+                (np.array_equal(ys[0], ys[-1], equal_nan=True) and np.array_equal(np.signbit(ys[0]), np.signbit(ys[-1]))), name
+            assert np.array_equal(ys[-1], ys["unaligned"], equal_nan=True), name
+            if np.all(np.abs(A.val) < 1e6):  # (the huge values of the other cases overflow to inf / nan in both)
+                yo = oracle.spmv(A, x)
+                scale = max(np.abs(A.to_scipy()).dot(np.abs(x)).max(), 1e-300)
+                assert np.max(np.abs(ys[-1] - yo)) <= KTOL * scale, name
+    finally:
+        ctx.set_option("spmv_valdict", -1)
+        ctx.set_option("force_rp64", -1)
+
+
+def test_spmv_sellwin_in_fused_cg(ctx, oracle):
+    """The fused (Ap, p) epilogue of form 4 sums over the same 256-row blocks and waves as the lane-per-row gather
+    form: the CG history is bit-identical to it, and within 1e-10 r0 of the oracle's (methods/cg.hpp:6-54);
+    in-place scaling drops the form and the next SpMV rebuilds it from the new values."""
+    n1 = 24
+    A = oracle.gen_hpcg(n1)
+    n = A.n_rows
+    hists = {}
+    try:
+        for sw in (0, -1):
+            ctx.set_option("spmv_sellwin", sw)
+            dA = ctx.gen_hpcg(n1)
+            assert dA.spmv_stream_info()[3] == (2 if sw == 0 else 4)
+            b, x = ctx.alloc(n), ctx.alloc(n)
+            ctx.init_vector(b, 1.0); ctx.init_vector(x, 0.1)
+            cg = ctx.cg(dA, b, x)
+            cg.init(1e-14)
+            cg.iterate(80)
+            iters, conv, hist = cg.status(hist_cap=128)
+            hists[sw] = (iters, np.array(hist), x.to_host())
+            cg.free(); dA.free(); b.free(); x.free()
+        assert hists[0][0] == hists[-1][0] and np.array_equal(hists[0][1], hists[-1][1]) and np.array_equal(hists[0][2], hists[-1][2])
+        ref = oracle.solve(A, "cg", "none")
+        m = min(len(ref["hist"]), len(hists[-1][1]))
+        assert np.max(np.abs(ref["hist"][:m] - hists[-1][1][:m])) <= 1e-10 * ref["hist"][0]
+        ctx.set_option("spmv_sellwin", -1)
+        A8 = oracle.gen_hpcg(8)
+        dA = ctx.matrix(A8)
+        xh = np.random.default_rng(5).uniform(-1, 1, A8.n_rows)
+        dx, dy = ctx.upload(xh), ctx.alloc(A8.n_rows)
+        ctx.spmv(dA, dx, dy)
+        assert dA.spmv_stream_info()[3] == 4
+        sv = ctx.scale_sym(dA).to_host()
+        ctx.spmv(dA, dx, dy)
+        B = CRS(A8.n_rows, A8.row_ptr, A8.col, A8.val * sv[np.repeat(np.arange(A8.n_rows), np.diff(A8.row_ptr))] * sv[A8.col])
+        assert np.max(np.abs(dy.to_host() - oracle.spmv(B, xh))) <= KTOL * np.abs(B.to_scipy()).dot(np.abs(xh)).max()
+    finally:
+        ctx.set_option("spmv_sellwin", -1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 777, 4096, 100001, 1 << 20])
