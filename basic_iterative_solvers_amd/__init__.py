@@ -299,6 +299,9 @@ class Context:
         return CG(self, A, b, x, A_D)
 
     # ---- measurement ---------------------------------------------------------
+    def stat(self, kind, A, D, b, x, Ls=None, Us=None):
+        return Stat(self, kind, A, D, b, x, Ls, Us)
+
     def profile(self, on):
         self.check(self.lib.bis_profile_enable(self.h, C.c_int(int(on))))
 
@@ -361,6 +364,16 @@ class Mat:
         self.ctx.check(self.ctx.lib.bis_mat_spmv_streamed_bytes(self.ctx.h, self.h, C.byref(b)))
         return b.value
 
+    def debug_ptrs(self):
+        """Device addresses (row_ptr, col, val) of the CRS arrays (bis_mat_debug_ptrs)."""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.ctx.check(self.ctx.lib.bis_mat_debug_ptrs(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def retune(self):
+        """Rebuild everything derived from the CRS arrays (bis_mat_retune): required after writing values in place."""
+        self.ctx.check(self.ctx.lib.bis_mat_retune(self.ctx.h, self.h))
+
     def set_grid_hint(self, nx, ny, nz, dof=1):
         self.ctx.check(self.ctx.lib.bis_mat_set_grid_hint(self.h, _i64(nx), _i64(ny), _i64(nz), C.c_int(dof)))
 
@@ -416,6 +429,40 @@ class CG:
 
 
 # ---- multi-GPU (1-D row partition) -------------------------------------------
+class Stat:
+    """Jacobi / Gauss-Seidel / symmetric Gauss-Seidel as device schedules (bis_stat_*)."""
+    KIND = {"j": 0, "gs": 1, "sgs": 2}
+
+    def __init__(self, ctx, kind, A, D, b, x, Ls=None, Us=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self._keep = (A, D, b, x, Ls, Us)
+        ctx.check(ctx.lib.bis_stat_create(ctx.h, C.c_int(self.KIND[kind]), A.h, Ls.h if Ls else None, Us.h if Us else None,
+                                          C.c_void_p(D.ptr), C.c_void_p(b.ptr), C.c_void_p(x.ptr), C.byref(self.h)))
+
+    def init(self, tol):
+        r0 = C.c_double()
+        self.ctx.check(self.ctx.lib.bis_stat_init(self.ctx.h, self.h, C.c_double(tol), C.byref(r0)))
+        return r0.value
+
+    def iterate(self, n):
+        self.ctx.check(self.ctx.lib.bis_stat_iterate(self.ctx.h, self.h, C.c_int(int(n))))
+
+    def status(self, hist_cap=4096):
+        it, conv = C.c_int(), C.c_int()
+        hist = np.zeros(hist_cap)
+        self.ctx.check(self.ctx.lib.bis_stat_status(self.ctx.h, self.h, C.byref(it), C.byref(conv), hist.ctypes, C.c_int(hist_cap)))
+        return it.value, bool(conv.value), hist[:min(it.value + 1, hist_cap)]
+
+    def solution(self, out):
+        self.ctx.check(self.ctx.lib.bis_stat_solution(self.ctx.h, self.h, C.c_void_p(out.ptr)))
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.bis_stat_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
 class CommOps(C.Structure):
     _fields_ = [("user", C.c_void_p),
                 ("allreduce_sum", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)),
@@ -507,6 +554,12 @@ class Dist:
         c, v, n, f = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self.ctx.check(self.ctx.lib.bis_dist_spmv_stream_info(self.ctx.h, self.h, C.byref(c), C.byref(v), C.byref(n), C.byref(f)))
         return c.value, v.value, n.value, f.value
+
+    def spmv_streamed_bytes(self):
+        """Bytes this rank's distributed SpMV moves at least per launch triple (bis_dist_spmv_streamed_bytes)."""
+        b = C.c_int64()
+        self.ctx.check(self.ctx.lib.bis_dist_spmv_streamed_bytes(self.ctx.h, self.h, C.byref(b)))
+        return b.value
 
     def profile_read(self):
         ne, na = C.c_int64(), C.c_int64()

@@ -47,6 +47,7 @@ struct bis_cg {
     double *hist = nullptr; // device residual history
     int hist_cap = 0;
     int enqueued = 0;
+    bool initialised = false; // bis_cg_init has run: p0 and (r,z) were made with the preconditioner set at that time
     unsigned *counters = nullptr; // device: arrival tickets of the last-arriver reductions ([0] pap, [1] pass B)
     // general preconditioner (bis_cg_set_preconditioner): z = M^-1 r through bis_apply_preconditioner
     int pc = -1;
@@ -293,7 +294,7 @@ bis_status bis_cg_set_preconditioner(bis_ctx *ctx, bis_cg *cg, int precond_type,
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, cg && precond_type >= BIS_PC_NONE && precond_type <= BIS_PC_ILU0 && outer_iters >= 1 && inner_iters >= 0,
                 "bis_cg_set_preconditioner: bad arguments");
-    BIS_REQUIRE(ctx, cg->enqueued == 0, "bis_cg_set_preconditioner: call it before bis_cg_init / bis_cg_iterate");
+    BIS_REQUIRE(ctx, !cg->initialised && cg->enqueued == 0, "bis_cg_set_preconditioner: call it before bis_cg_init / bis_cg_iterate");
     if (cg->z == cg->r) { // z aliased r (no preconditioner at creation): it needs its own storage now
         cg->z = nullptr;
         bis_status st = bis_vec_alloc(ctx, cg->n, &cg->z);
@@ -363,6 +364,7 @@ bis_status bis_cg_init(bis_ctx *ctx, bis_cg *cg, double tol, double *r0_norm_hos
     BIS_HIP_CHECK(ctx, hipMemcpyAsync(cg->hist, &norm0, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     cg->enqueued = 0;
+    cg->initialised = true;
     if (r0_norm_host) *r0_norm_host = norm0;
     return BIS_OK;
 }
@@ -424,7 +426,7 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
     // HPCG-32/64/128/256: 2.33/4.83/40.6/607 ms of plain launches against 2.66/5.73/42.8/588 ms of replays)
     for (int done = 0; done < n_iters; ++done) {
         st = cg_enqueue_iteration(ctx, cg, g, cg->enqueued + done + 1);
-        if (st != BIS_OK) return st;
+        if (st != BIS_OK) { cg->enqueued += done; return st; } // (pass C's iteration numbers must keep matching the device's count)
     }
     BIS_HIP_CHECK(ctx, hipGetLastError());
     cg->enqueued += n_iters;

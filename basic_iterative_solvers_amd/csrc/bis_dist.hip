@@ -612,6 +612,20 @@ bis_status bis_dist_spmv_stream_info(bis_ctx *ctx, const bis_dist *d, int *col_b
     return bis_mat_spmv_stream_info(ctx, d->mid, col_bytes, val_bytes, n_dict, form);
 }
 
+bis_status bis_dist_spmv_streamed_bytes(bis_ctx *ctx, const bis_dist *d, int64_t *bytes) {
+    BIS_CTX_OK(ctx);
+    BIS_REQUIRE(ctx, d && d->mid && bytes, "bis_dist_spmv_streamed_bytes: bad arguments");
+    int64_t tot = 8 * d->A->n_cols; // x = [owned | halo], once for the three launches
+    for (const bis_mat *v : {d->lo, d->mid, d->hi}) {
+        int64_t b = 0;
+        if (v->n_rows == 0) continue;
+        if (bis_status st = bis_mat_spmv_streamed_bytes(ctx, v, &b)) return st;
+        tot += b - 8 * v->n_cols;
+    }
+    *bytes = tot;
+    return BIS_OK;
+}
+
 bis_status bis_dist_profile_read(bis_ctx *ctx, bis_dist *d, int64_t *n_exchange, double *exchange_ms,
                                  int64_t *n_allreduce, double *allreduce_ms) {
     BIS_CTX_OK(ctx);

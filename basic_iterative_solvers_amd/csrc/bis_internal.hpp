@@ -85,6 +85,8 @@ struct bis_options {
     int trsv_tile_edge = -1; // grid-hinted matrices: tile extents in nodes, e (cubic) or ex | ey << 8 | ez << 16 (default by row length; 0 = interval tiles of the natural order)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
     int spmv_sellwin = -1; // dictionary SpMV with the block's x window in LDS and sliced-ELL codes (bis_spmv_sell.hip): 0 off (-1: on where the matrix qualifies)
+    int device_share = -1;  // k > 1: this device is shared by k processes that all run persistent grids (several ranks on one GPU in a test
+                            // or rehearsal): kernels that need their whole grid resident keep to 1/k of the device
     int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes
 };
 // row_ptr width of a new matrix: int64 when the non-zeros (plus the stream padding) do not fit int32
@@ -289,6 +291,8 @@ void bis_spmv_sellwin_drop(bis_mat *A);
 bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t);
 // free row-block tables, packed streams and window structures (not the CRS arrays)
 void bis_mat_free_meta(bis_mat *A);
+// after the values of A changed in place: drops every structure derived from them (dictionaries, code streams, sweep plans)
+void bis_mat_values_changed(bis_mat *A);
 void bis_trsv_plan_destroy(bis_trsv_plan *p);
 bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
                                      bis_mat **U_strict, double *D, double *D_inv, bool check_diag);

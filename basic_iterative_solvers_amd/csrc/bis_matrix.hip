@@ -402,6 +402,20 @@ bis_status finalize_t(bis_ctx *ctx, bis_mat *A) {
 
 } // namespace
 
+// The values of A changed in place (bis_mat_scale_sym; a caller that wrote through bis_mat_debug_ptrs and then calls
+// bis_mat_retune): everything derived from them goes -- value dictionary and code streams, the tiled sweeps' plans (they
+// hold a copy of the values in their entry stream), the level plans (their row views carry dictionaries of their own).
+void bis_mat_values_changed(bis_mat *A) {
+    bis_spmv_drop_valdict(A);
+    bis_trsv_tiled_destroy(A->tiled_fwd);
+    bis_trsv_tiled_destroy(A->tiled_bwd);
+    A->tiled_fwd = A->tiled_bwd = nullptr;
+    A->tiled_tried_fwd = A->tiled_tried_bwd = false;
+    bis_trsv_plan_destroy(A->plan_fwd);
+    bis_trsv_plan_destroy(A->plan_bwd);
+    A->plan_fwd = A->plan_bwd = nullptr;
+}
+
 void bis_mat_free_meta(bis_mat *A) {
     hipFree(A->blk_row); hipFree(A->blk_nnz); hipFree(A->blkf_row); hipFree(A->blkf_nnz);
     A->blk_row = A->blkf_row = nullptr;
@@ -630,6 +644,7 @@ BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A) {
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, A, "bis_mat_retune: null matrix");
     BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    bis_mat_values_changed(A); // (the tuning tools may also have written the arrays through bis_mat_debug_ptrs)
     return bis_mat_finalize(ctx, A);
 }
 

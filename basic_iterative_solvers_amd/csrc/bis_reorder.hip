@@ -372,7 +372,8 @@ bis_status bis_mat_scale_sym(bis_ctx *ctx, bis_mat *A, double *scale) {
     BIS_REQUIRE(ctx, A && scale && !A->view && A->n_rows == A->n_cols, "bis_mat_scale_sym: bad arguments");
     const int64_t n = A->n_rows;
     if (n == 0) return BIS_OK;
-    bis_spmv_drop_valdict(A); // the values change in place
+    BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // sweeps in flight still read the plans dropped next
+    bis_mat_values_changed(A); // the values change in place
     unsigned long long *status = (unsigned long long *)(ctx->scalars_dev + 32);
     BIS_HIP_CHECK(ctx, hipMemsetAsync(status, 0xFF, 8, ctx->stream));
     const unsigned grid = (unsigned)((n + 255) / 256);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     int n_blocks_pad8, const double *w, double *partials, const uint16_t *__restrict__ pk,
     int64_t pk_base, const int32_t *__restrict__ seg_base, int col_max, const int *stop) {
     constexpr bool FUSE_DOT = MODE == 1;
-    if (MODE == 1 && stop && stop[1]) return; // the solver has stopped: this iteration is a no-op
+    if (stop && stop[1]) return; // the solver has stopped: this launch is a no-op
     extern __shared__ __attribute__((aligned(16))) double prod[];
     const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8)
                                     : (n_blocks_pad8 < -1 ? xcd_group_remap(blockIdx.x, -n_blocks_pad8) : (int)blockIdx.x);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void spmv_rowblock_vd_kernel(
     const uint8_t *__restrict__ vcode, int64_t vd_base, const double *__restrict__ vdict) {
     constexpr int T = 256, J = 8;
     constexpr bool FUSE_DOT = MODE == 1;
-    if (MODE == 1 && stop && stop[1]) return;
+    if (stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) double prod[];
     __shared__ double dict[256];
     const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8)
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void spmv_rowmajor_vd_kernel(
     const int *stop, const uint8_t *__restrict__ vcode, int64_t vd_base, const double *__restrict__ vdict, int code_cap,
     const double *__restrict__ vdiag) {
     constexpr bool FUSE_DOT = MODE == 1;
-    if (FUSE_DOT && stop && stop[1]) return;
+    if (stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ double dict[256];
     const int b = n_blocks_pad8 > 0 ? xcd_remap(blockIdx.x, n_blocks_pad8)
@@ -1312,7 +1312,7 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     a.remap_arg = remap_arg_for(nb8);
     a.grid = grid_for_map(nb, a.remap_arg);
     if (bis_status st = ensure_packed(ctx, A, use_f ? 1 : 0, &a)) return st;
-    a.stop = w ? ctx->spmv_stop : nullptr;
+    a.stop = ctx->spmv_stop; // a device schedule (bis_cg_iterate, bis_stat_iterate) is enqueuing: no-op once its stop flag is set
     {
         bool done = false;
         if (bis_status st = launch_sellwin(ctx, A, a, x, y, w ? 1 : 0, w, ctx->partials, partials_off, n_partials, &done)) return st;
@@ -1350,6 +1350,7 @@ bis_status bis_spmv_trsv_level(bis_ctx *ctx, const bis_mat *T, const double *x, 
     a.remap_arg = remap_arg_for(nb8);
     a.grid = grid_for_map(nb, a.remap_arg);
     if (bis_status st = ensure_packed(ctx, T, 0, &a)) return st;
+    a.stop = ctx->spmv_stop;
     {
         bool done = false;
         if (bis_status st = launch_rowmajor(ctx, T, a, x, y, 2, b, const_cast<double *>(D), 0, nullptr, &done)) return st;

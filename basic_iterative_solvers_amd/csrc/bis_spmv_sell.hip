@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
     const uint32_t *__restrict__ codes, const double *__restrict__ dict_g, const double *__restrict__ vdiag, int x_al16) {
     using L = SwLayout<DIAG, SMALL>;
-    if (MODE == 1 && stop && stop[1]) return;
+    if (stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int b = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
                                 : (remap_arg < -1 ? xcd_group_remap(blockIdx.x, -remap_arg) : (int)blockIdx.x);

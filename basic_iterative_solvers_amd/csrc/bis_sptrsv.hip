@@ -71,10 +71,18 @@ namespace {
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
 constexpr int kTrsvT = 256;
-constexpr unsigned kSpinLimit = 1u << 22; // polls of one row before it gives up and publishes NaN (seconds)
+constexpr unsigned kSpinLimit = 1u << 20; // polls of one row before it gives up and publishes NaN (about a second)
+constexpr unsigned kFaultPollMask = 1023u; // a waiting row reads the context's fault word every 1024 polls: once ANY wait of the
+                                           // sweep has given up, every other wait ends within a millisecond and later rows do not
+                                           // wait at all -- a starved or lost hand-off drains the grid at once instead of row by row
+__device__ __forceinline__ bool fault_raised(const unsigned *fault) {
+    return __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+}
 constexpr int kWaveBlocksPerCU = 4;       // wave-per-row kernel: resident workgroups per CU the launch bound guarantees
 
-__global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned long long *xs, int64_t n) {
+// ... and the sweep's ticket counter / elected XCD (none yet): set on the device, in stream order by construction
+__global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned long long *xs, int64_t n, unsigned *ticket) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ticket[0] = 0u; ticket[1] = 0xffffffffu; }
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) xs[i] = kSentinel;
 }
@@ -92,8 +100,9 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
     const RP *__restrict__ row_ptr, const int32_t *__restrict__ dep /* col, or positions (pcol) */,
     const double *__restrict__ val, const int32_t *__restrict__ perm, int64_t n,
     const double *__restrict__ D, const double *b, double *x, unsigned long long *xs,
-    unsigned *ticket, int by_pos, unsigned *fault) {
+    unsigned *ticket, int by_pos, unsigned *fault, const int *stop) {
     __shared__ unsigned s_ticket;
+    if (stop && stop[1]) return; // the device schedule this sweep belongs to has stopped: x stays as it is
     if (ONE_XCD) {
         if (threadIdx.x == 0) {
             unsigned my;
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
         __syncthreads();
         if (!go) return;
     }
+    bool aborted = false; // this lane has seen the sweep fail: its later rows do not wait any more
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
         __syncthreads();
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
             const double rhs = valid ? b[r] : 0.0, d = valid ? D[r] : 1.0;
             const int64_t slot = by_pos ? pos : (int64_t)r; // where this row's result is published
             double acc = 0.0;
-            unsigned spins = 0;
+            unsigned spins = aborted ? kSpinLimit : 0u;
             // One loop, bounded work per trip (lanes of one wave may depend on each
             // other, so no lane may spin in a loop of its own): a batch of up to
             // kBatch dependencies is loaded with independent loads (one round trip),
@@ -181,8 +191,11 @@ __global__ __launch_bounds__(kTrsvT) void sptrsv_syncfree_kernel(
                     }
                 }
                 if (ready < in_batch) { // still pending
-                    if (++spins > kSpinLimit) { // bounded: a lost hand-off must not hang the GPU -- publishes NaN and
-                        publish = true;         // raises the context's fault word (the next blocking call fails)
+                    ++spins;
+                    if ((spins & kFaultPollMask) == 0u && fault_raised(fault)) spins = kSpinLimit + 1u; // somebody gave up: so do we
+                    if (spins > kSpinLimit) { // bounded: a lost hand-off must not hang the GPU -- publishes NaN and
+                        publish = true;       // raises the context's fault word (the next blocking call fails)
+                        aborted = true;
                         __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     } else __builtin_amdgcn_s_sleep(1);
                 }
@@ -226,7 +239,8 @@ template <typename RP>
 __global__ __launch_bounds__(kTrsvT, kWaveBlocksPerCU) void sptrsv_wave_kernel(
     const RP *__restrict__ row_ptr, const int32_t *__restrict__ dep, const double *__restrict__ val,
     const int32_t *__restrict__ perm, int64_t n, const double *__restrict__ D, const double *b, double *x,
-    unsigned long long *xs, unsigned *ticket, int by_pos, unsigned *fault) {
+    unsigned long long *xs, unsigned *ticket, int by_pos, unsigned *fault, const int *stop) {
+    if (stop && stop[1]) return;
     const int lane = threadIdx.x & 63;
     // Static round robin over the level-sorted positions, no ticket counter (one atomic
     // per row on one address caps the sweep at ~88 M rows/s: 11.4 ns per row measured).
@@ -235,6 +249,7 @@ __global__ __launch_bounds__(kTrsvT, kWaveBlocksPerCU) void sptrsv_wave_kernel(
     // grid are resident -- the launch keeps the grid at <= 4 workgroups per CU.
     const int64_t n_waves = (int64_t)gridDim.x * (kTrsvT / 64);
     const int64_t wave0 = (int64_t)blockIdx.x * (kTrsvT / 64) + (threadIdx.x >> 6);
+    bool aborted = false; // the sweep has failed (this wave or another gave up): no further waiting
     for (int64_t pos = wave0; pos < n; pos += n_waves) {
         const int r = perm[pos];
         const int64_t s = (int64_t)row_ptr[r], e = (int64_t)row_ptr[r + 1];
@@ -272,8 +287,11 @@ __global__ __launch_bounds__(kTrsvT, kWaveBlocksPerCU) void sptrsv_wave_kernel(
                 }
                 folded = upto;
                 if (!pend) break;
-                if (++spins > kSpinLimit) { // bounded: publishes NaN below and raises the context's fault word
+                ++spins;
+                if (!aborted && (spins & kFaultPollMask) == 0u) aborted = __builtin_amdgcn_readfirstlane((int)fault_raised(fault)) != 0;
+                if (aborted || spins > kSpinLimit) { // bounded: publishes NaN below and raises the context's fault word
                     lost = true;
+                    aborted = true;
                     if (lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
@@ -332,7 +350,8 @@ __global__ __launch_bounds__(256) void trsv_level_kernel(const RP *__restrict__ 
                                                          const int32_t *__restrict__ perm,
                                                          int64_t begin, int64_t end,
                                                          const double *__restrict__ D, const double *b,
-                                                         double *x) {
+                                                         double *x, const int *stop) {
+    if (stop && stop[1]) return;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = begin + (int64_t)blockIdx.x * 256 + threadIdx.x; i < end; i += stride) {
         const int r = perm[i];
@@ -525,19 +544,17 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
             const int grid = (int)std::min<int64_t>((hi - lo + 255) / 256, (int64_t)ctx->n_cus * 32);
             if (T->rp64)
                 hipLaunchKernelGGL(trsv_level_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream,
-                                   (const int64_t *)T->row_ptr, T->col, T->val, p->perm, lo, hi, D, b, x);
+                                   (const int64_t *)T->row_ptr, T->col, T->val, p->perm, lo, hi, D, b, x, ctx->spmv_stop);
             else
                 hipLaunchKernelGGL(trsv_level_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream,
-                                   (const int32_t *)T->row_ptr, T->col, T->val, p->perm, lo, hi, D, b, x);
+                                   (const int32_t *)T->row_ptr, T->col, T->val, p->perm, lo, hi, D, b, x, ctx->spmv_stop);
         }
         BIS_HIP_CHECK(ctx, hipGetLastError());
         return BIS_OK;
     }
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,
-                       (unsigned long long *)p->xs, n + 1);
-    static const unsigned tk[2] = {0u, 0xffffffffu}; // ticket counter, elected XCD (none yet)
-    BIS_HIP_CHECK(ctx, hipMemcpyAsync(p->ticket, tk, sizeof tk, hipMemcpyHostToDevice, ctx->stream));
+                       (unsigned long long *)p->xs, n + 1, p->ticket);
     // persistent grid: resident by construction (<= 8 workgroups of 256 per CU, 51 VGPRs)
     const int64_t n_tickets = (n + kTrsvT - 1) / kTrsvT;
     // Only ~one level is runnable at a time: keep a few of the widest levels
@@ -621,22 +638,25 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
         }
         int64_t wg = (4 * p->max_level_width + 3) / 4 + 1;
         if (bis_opts().trsv_grid > 0) wg = bis_opts().trsv_grid;
-        wg = std::max<int64_t>(1, std::min<int64_t>(wg, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->n_cus * res)));
+        // option "device_share" = k: k processes run sweeps on this device at the same time (ranks of a test or a rehearsal
+        // sharing one GPU), each keeps to 1/k of the residency so that all their grids fit together
+        const int share = std::max(1, bis_opts().device_share);
+        wg = std::max<int64_t>(1, std::min<int64_t>(wg, std::min<int64_t>((n + 3) / 4, std::max<int64_t>(1, (int64_t)ctx->n_cus * res / share))));
         if (T->rp64)
             hipLaunchKernelGGL(sptrsv_wave_kernel<int64_t>, dim3((unsigned)wg), dim3(kTrsvT), 0, ctx->stream,
                                (const int64_t *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,
-                               (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev);
+                               (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev, ctx->spmv_stop);
         else
             hipLaunchKernelGGL(sptrsv_wave_kernel<int32_t>, dim3((unsigned)wg), dim3(kTrsvT), 0, ctx->stream,
                                (const int32_t *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,
-                               (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev);
+                               (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev, ctx->spmv_stop);
         BIS_HIP_CHECK(ctx, hipGetLastError());
         return BIS_OK;
     }
 #define BIS_TRSV_LAUNCH(RP, ONE, B)                                                                    \
     hipLaunchKernelGGL((sptrsv_syncfree_kernel<RP, ONE, B>), dim3(grid), dim3(kTrsvT), 0, ctx->stream, \
                        (const RP *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,                      \
-                       (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev)
+                       (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev, ctx->spmv_stop)
 #define BIS_TRSV_B(RP, ONE)                                                                            \
     do {                                                                                               \
         if (batch >= 32) BIS_TRSV_LAUNCH(RP, ONE, 32);                                                 \

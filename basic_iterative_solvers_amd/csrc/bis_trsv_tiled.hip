@@ -83,8 +83,8 @@ using CfgLean = TiledCfg<512, 512, 128, 128, 256, 64, 128>;
 using CfgWide = TiledCfg<1024, 1024, 256, 256, 512, 128, 256>;
 constexpr int kMaxB = 32768;      // rows per tile at most
 constexpr int kPollBlock = 128;   // external ordinals the poller has in flight (2 per lane); its watermark moves with the leading delivered ordinal
-constexpr unsigned kSpinLds = 1u << 24;  // polls of an LDS word before a wave gives up (seconds)
-constexpr unsigned kSpinMem = 1u << 22;  // polls of a memory word
+constexpr unsigned kSpinLds = 1u << 26;  // polls of an LDS word before a wave gives up (several seconds: longer than the poller's budget below)
+constexpr unsigned kSpinMem = 1u << 20;  // polls of a memory word (about a second)
 
 enum { C_TICKET = 0, C_Q_LOADED, C_Q_DONE, C_SLOT_LOADED, C_SLOT_DONE, C_EXT_WM, C_EXT_SAFE, C_N = 8 };
 
@@ -134,6 +134,7 @@ struct TiledArgs {
     const double *D, *b;
     double *x;
     unsigned *fault;
+    const int *stop; // a device schedule's stop flag (flags[1]): the sweep is a no-op once it is set
     int n_tiles;
     long long *dbg; // DBG only, 8 words per tile: start, end (s_memrealtime, 100 MHz), core cycles the compute wave waited for the
                     // loaders / for external operands, end of the quad loader / slot loader / poller, steps
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
     __shared__ double2 ring_bD[kRingSlot];
     __shared__ unsigned ctl[C_N];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (a.stop && a.stop[1]) return;
     if (threadIdx.x == 0) opnd[kZeroSlot] = 0ull;
     for (;;) {
         if (threadIdx.x == 0) ctl[C_TICKET] = atomicAdd(a.ticket, 1u);
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     }
                     const long long t1 = DBG ? (long long)__builtin_readcyclecounter() : 0;
                     if (DBG) w_load += t1 - t0;
+                    spins = 0; // (a budget of its own: the poller, which always moves the watermark on, gives up long before it runs out)
                     for (;;) {
                         ext_wm = (int)lds_acquire(&ctl[C_EXT_WM]);
                         if (ext_wm >= ext_end) break;
@@ -223,11 +226,13 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     }
                     if (DBG) w_ext += (long long)__builtin_readcyclecounter() - t1;
                 }
-                const int sl = (slot_b + lane) & (kRingSlot - 1);
+                // lanes past the step's width take the last row's slots (loaded, in range); their results are masked at the store
+                const int wl = min(lane, w - 1);
+                const int sl = (slot_b + wl) & (kRingSlot - 1);
                 const int row = ring_row[sl];
                 const double2 bd = ring_bD[sl];
                 double acc = 0.0;
-                int qi = quad_b + lane;
+                int qi = quad_b + wl;
                 for (int g = 0; g < nq; ++g, qi += w) {
                     const int4 c = ring_code[qi & (kRingQ - 1)];
                     const double2 v01 = ring_val[2 * (qi & (kRingQ - 1))], v23 = ring_val[2 * (qi & (kRingQ - 1)) + 1];
@@ -361,7 +366,9 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     unsigned long long vb[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) vb[u] = got[u] ? 0ull : __hip_atomic_load(&a.xs[src[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool give_up = ++spins > kSpinMem;
+                    // ... or as soon as any wait of the sweep has raised the fault word: the grid then drains at once
+                    ++spins;
+                    const bool give_up = spins > kSpinMem || ((spins & 255u) == 0u && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
                     bool all = true;
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -1126,7 +1133,7 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, p->xs, p->n + 1);
     BIS_HIP_CHECK(ctx, hipMemsetAsync(p->ticket, 0, sizeof(unsigned) * 4, ctx->stream));
     TiledArgs a{p->slot_row, p->step_desc, p->tile_slot0, p->tile_step0, p->tile_quad0, p->tile_ext0, p->quad_code, p->quad_val,
-                p->ext_src, p->xs, p->ticket, D, b, x, ctx->fault_dev, p->n_tiles, nullptr};
+                p->ext_src, p->xs, p->ticket, D, b, x, ctx->fault_dev, ctx->spmv_stop, p->n_tiles, nullptr};
     static long long *dbg_buf = nullptr; // diagnostic (BIS_TRSV_TILE_DEBUG=file): per-tile stamps of the last sweep
     static int64_t dbg_cap = 0;
     const char *dbg_file = getenv("BIS_TRSV_TILE_DEBUG");

@@ -75,7 +75,7 @@ struct Args {
     PrecondType preconditioner{};
     int restart_length = 10;
     bool num_scale = false;
-    bool unfused = false; // -unfused: CG runs the reference's kernel-by-kernel schedule
+    bool unfused = false; // -unfused: CG / Jacobi / GS / SGS run the reference's kernel-by-kernel schedule (blocking reductions) instead of the device schedules
     bool host_scalars = false; // -hostscalars: GMRES / BiCGSTAB return every dot product to the host like the reference
                                // (default: Gram-Schmidt coefficients, alpha / omega / beta stay on the device)
     std::string perm_mode = "none"; // -perm mc: multi-colour reordering (SMAX PERM_MODE role)

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "../solver.hpp"
+#include "jacobi.hpp" // run_stat_schedule
 
 inline void gs_separate_iteration(Timers *timers, const MatrixCRS *U, const MatrixCRS *L, double *tmp,
                                   const double *D, const double *b, double *x) {
@@ -21,7 +22,13 @@ inline void bgs_separate_iteration(Timers *timers, const MatrixCRS *U, const Mat
 class GaussSeidelSolver : public Solver {
   public:
     double *x = nullptr;
-    explicit GaussSeidelSolver(const Args *a) : Solver(a) {}
+    // device schedule (bis_stat_*, the default; -unfused: the reference's blocking norm per iteration): the same
+    // operations in the same order, norm and stopping test on the device, sweeps and SpMVs no-ops once it has fired
+    bool fused = false;
+    bis_stat *fst = nullptr;
+    std::vector<double> fused_hist;
+    explicit GaussSeidelSolver(const Args *a) : Solver(a) { fused = !a->unfused && residual_check_len == 1; }
+    virtual int stat_kind() const { return BIS_STAT_GS; }
     void allocate_structs(const int n) override {
         Solver::allocate_structs(n);
         x = dalloc(n);
@@ -31,11 +38,21 @@ class GaussSeidelSolver : public Solver {
         copy_vector(x, x_0, n);
     }
     void init_residual() override {
+        if (fused) {
+            bis::check(bis_stat_create(bis::ctx(), stat_kind(), A->dev, L_strict->dev, U_strict->dev, A_D, b, x, &fst), "bis_stat_create");
+            bis::check(bis_stat_init(bis::ctx(), fst, tolerance, &residual_norm), "bis_stat_init");
+            collected_residual_norms[collected_residual_norms_count++] = residual_norm;
+            return;
+        }
         compute_residual(A.get(), x, b, residual, tmp);
         residual_norm = euclidean_vec_norm(residual, N);
         Solver::init_residual();
     }
     void iterate(Timers *timers) override {
+        if (fused) { // (chunks of 8: the launches behind the stopping iteration are no-ops, but many)
+            if (fused_hist.empty()) run_stat_schedule(timers, fst, max_iters, 8, fused_hist);
+            return;
+        }
         gs_separate_iteration(timers, U_strict.get(), L_strict.get(), tmp, A_D, b, x);
     }
     void exchange() override {}
@@ -44,17 +61,26 @@ class GaussSeidelSolver : public Solver {
         Solver::save_x_star();
     }
     void record_residual_norm() override {
-        compute_residual(A.get(), x, b, residual, tmp);
-        residual_norm = euclidean_vec_norm(residual, N);
+        if (fused) {
+            residual_norm = fused_hist[std::min<size_t>(iter_count, fused_hist.size() - 1)];
+        } else {
+            compute_residual(A.get(), x, b, residual, tmp);
+            residual_norm = euclidean_vec_norm(residual, N);
+        }
         Solver::record_residual_norm();
     }
-    ~GaussSeidelSolver() override { dfree(x); }
+    ~GaussSeidelSolver() override {
+        if (fst) bis_stat_destroy(bis::ctx(), fst);
+        dfree(x);
+    }
 };
 
 class SymmetricGaussSeidelSolver : public GaussSeidelSolver {
   public:
     explicit SymmetricGaussSeidelSolver(const Args *a) : GaussSeidelSolver(a) {}
+    int stat_kind() const override { return BIS_STAT_SGS; }
     void iterate(Timers *timers) override {
+        if (fused) { GaussSeidelSolver::iterate(timers); return; }
         gs_separate_iteration(timers, U_strict.get(), L_strict.get(), tmp, A_D, b, x);
         bgs_separate_iteration(timers, U_strict.get(), L_strict.get(), tmp, A_D, b, x);
     }

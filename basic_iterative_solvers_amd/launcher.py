@@ -82,13 +82,24 @@ def torch_comm_ops(td, torch, n_ranks, rank, group=None):
     import os
     trace = os.environ.get("BIS_DIST_TRACE") == "1"
 
+    # gloo reduces host memory: stage the (tiny) device buffers through CPU tensors explicitly -- wait for the
+    # library's stream, copy out, reduce, copy back -- instead of handing gloo device tensors
+    host_staged = td.get_backend(group) == "gloo"
+
     def allreduce(user, stream, buf, count):
         if trace:
             print(f"rank {rank}: allreduce({count}) enter", flush=True)
         try:
             with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
                 t = wrap(buf, count)
-                td.all_reduce(t, group=group)
+                if host_staged:
+                    h = t.cpu()
+                    if trace:
+                        print(f"rank {rank}: allreduce({count}) stream drained", flush=True)
+                    td.all_reduce(h, group=group)
+                    t.copy_(h)
+                else:
+                    td.all_reduce(t, group=group)
             if trace:
                 print(f"rank {rank}: allreduce({count}) done", flush=True)
             return 0
@@ -103,17 +114,26 @@ def torch_comm_ops(td, torch, n_ranks, rank, group=None):
             with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
                 torch.cuda.current_stream().synchronize()
                 ops, so, ro = [], 0, 0
+                back = []
                 for p in range(n):
                     sc, rc = int(send_counts[p]), int(recv_counts[p])
                     if sc:
-                        ops.append(td.P2POp(td.isend, wrap(sendbuf + 8 * so, sc), p, group))
+                        st = wrap(sendbuf + 8 * so, sc)
+                        ops.append(td.P2POp(td.isend, st.cpu() if host_staged else st, p, group))
                     if rc:
-                        ops.append(td.P2POp(td.irecv, wrap(recvbuf + 8 * ro, rc), p, group))
+                        rt = wrap(recvbuf + 8 * ro, rc)
+                        if host_staged:
+                            hr = torch.empty(rc, dtype=torch.float64)
+                            back.append((rt, hr))
+                            rt = hr
+                        ops.append(td.P2POp(td.irecv, rt, p, group))
                     so += sc
                     ro += rc
                 if ops:  # batched: safe for both gloo and nccl process groups
                     for r in td.batch_isend_irecv(ops):
                         r.wait()
+                for rt, hr in back:
+                    rt.copy_(hr)
                 torch.cuda.current_stream().synchronize()
             if trace:
                 print(f"rank {rank}: exchange done", flush=True)

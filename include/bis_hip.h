@@ -182,7 +182,10 @@ BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
  * first_ms / best_ms (optional): SpMV time before and after. */
 BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_trials,
                                           double *first_ms, double *best_ms);
-/* device addresses of the CRS arrays (tuning / zero-copy interop) */
+/* device addresses of the CRS arrays (tuning / zero-copy interop).  A caller that
+ * writes VALUES through them must call bis_mat_retune afterwards: the library
+ * caches re-encodings of the values (dictionary code streams, the tiled sweeps'
+ * entry streams) that bis_mat_retune and bis_mat_scale_sym drop. */
 BIS_API bis_status bis_mat_debug_ptrs(const bis_mat *A, void **row_ptr,
                                       void **col, void **val);
 /* copy the device CRS back (tests: bit-exact CRS checks); any pointer may be
@@ -418,6 +421,38 @@ BIS_API bis_status bis_kernel_run(bis_ctx *ctx, const char *name,
                                   int64_t C_offset);
 BIS_API bis_status bis_kernel_swap_operands(bis_ctx *ctx, const char *name);
 
+/* ---- stationary solvers as device schedules (methods/jacobi.hpp:43-52, :79-107;
+ * methods/gauss_seidel.hpp:26-52, :76-105, :119-129) -------------------------
+ * Jacobi, Gauss-Seidel and symmetric Gauss-Seidel as SOLVERS: iteration, true
+ * residual b - A x of every iterate (record_residual_norm), its norm and
+ * check_stopping_criteria (solver.hpp:177-192) run on the device; no host read
+ * per iteration.  Jacobi makes ONE SpMV per iteration -- the product A x_k that
+ * samples iteration k's residual is the one iteration k+1 starts from -- and
+ * fuses residual, norm partials and the step into one pass; the sampled norms are
+ * bit-identical to bis_compute_residual + bis_euclidean_vec_norm.  GS / SGS run
+ * the reference's operations unchanged, stream-ordered.  After the stop test has
+ * fired the remaining enqueued launches are no-ops (SpMVs and sweeps included).
+ * x: x_0 on entry; read the result with bis_stat_solution (Jacobi alternates
+ * between x and a buffer of its own).  D = diagonal of A; L_strict / U_strict
+ * (bis_mat_split_strict) are needed for GS / SGS only. */
+enum { BIS_STAT_JACOBI = 0, BIS_STAT_GS = 1, BIS_STAT_SGS = 2 };
+typedef struct bis_stat bis_stat;
+BIS_API bis_status bis_stat_create(bis_ctx *ctx, int kind, const bis_mat *A,
+                                   const bis_mat *L_strict, const bis_mat *U_strict,
+                                   const double *D, const double *b, double *x,
+                                   bis_stat **out);
+/* init_residual: ||b - A x_0|| (returned), stopping threshold tol * that. */
+BIS_API bis_status bis_stat_init(bis_ctx *ctx, bis_stat *s, double tol,
+                                 double *r0_norm_host);
+/* enqueue n_iters iterations (no synchronisation) */
+BIS_API bis_status bis_stat_iterate(bis_ctx *ctx, bis_stat *s, int n_iters);
+/* blocking: iterations executed, converged flag, residual history [0..iters] */
+BIS_API bis_status bis_stat_status(bis_ctx *ctx, bis_stat *s, int *iters,
+                                   int *converged, double *hist_host, int hist_cap);
+/* blocking: the iterate the last history entry belongs to, copied to x_out */
+BIS_API bis_status bis_stat_solution(bis_ctx *ctx, bis_stat *s, double *x_out);
+BIS_API bis_status bis_stat_destroy(bis_ctx *ctx, bis_stat *s);
+
 /* ---- fused CG schedule (cg.hpp:6-54 + :162-166, same arithmetic, fewer
  * passes; SURVEY.md section 8d "fused lower bound") -------------------------- */
 typedef struct bis_cg bis_cg;
@@ -566,6 +601,11 @@ BIS_API bis_status bis_dist_stats(const bis_dist *d, int64_t *n_halo,
 BIS_API bis_status bis_dist_spmv_stream_info(bis_ctx *ctx, const bis_dist *d,
                                              int *col_bytes, int *val_bytes,
                                              int *n_dict, int *form);
+/* bis_mat_spmv_streamed_bytes of this rank's distributed SpMV: the stream formats
+ * of its three row ranges (boundary, interior, boundary), x = [owned | halo] and
+ * y once. */
+BIS_API bis_status bis_dist_spmv_streamed_bytes(bis_ctx *ctx, const bis_dist *d,
+                                                int64_t *bytes);
 /* While bis_profile_enable is on, every halo exchange (on the communication
  * stream) and every scalar all-reduce (on the compute stream) is bracketed by
  * HIP events; returns counts and summed milliseconds and resets (blocking). */

@@ -192,9 +192,12 @@ def main():
         assert np.max(np.abs(xv.to_host() - ref_cg["x"][row0:row1])) <= 1e-9
         cg.free()
         print(f"rank {rank}: distributed SpMV / dot / Jacobi-CG done", flush=True)
-        if world <= int(os.environ.get("BIS_TEST_BJ_MAX_WORLD", "1")):  # ranks sharing ONE GPU: the sweeps' many small launches next to the
-            # gloo callbacks of three processes stalled the shared device intermittently (a test-rig artefact: one process per GPU in production);
-            # the multi-rank mathematics of the block preconditioner is covered on the CPU (mode cpu), the device path here with one rank
+        if True:
+            # `world` processes share ONE GPU here and all run persistent sweep grids at the same time: option
+            # "device_share" keeps every residency-bound grid (the wave-per-row sweep deals its rows statically) to
+            # 1 / world of the device, so that the grids of all ranks fit together.  Without it a starved grid ends in
+            # BIS_ERR_SYNC after about a second (every wait polls the fault word), never in a hang.
+            ctx.set_option("device_share", world)
             # ---- block-Jacobi of the sweeps: every rank preconditions with SGS / ILU(0) of ITS diagonal block
             # (bis_mat_diag_block -> bis_mat_split_strict / bis_mat_ilu0 -> bis_cg_set_preconditioner).  Reference: the
             # same PCG with the block-diagonal preconditioner assembled from oracle sweeps on the blocks.

@@ -707,12 +707,118 @@ def test_sptrsv_lost_handoff_is_reported(ctx, oracle, kind, size):
     ctx.sptrsv(dLs, x, dD, db)               # builds the plan and the position table
     assert np.array_equal(x.to_host(), want)
     ctx.set_option("trsv_inject_loss", Ls.nnz // 2)
-    ctx.sptrsv(dLs, x, dD, db)
+    ctx.sptrsv(dLs, x, dD, db)               # (builds the level plan: the hook lives in the level-scheduled sweeps)
     with pytest.raises(BisError, match="lost a hand-off"):
         ctx.sync()
     ctx.sync()                               # reported once
     ctx.sptrsv(dLs, x, dD, db)
     assert np.array_equal(x.to_host(), want)
+    # wall time of a failing sweep: the first wait gives up after its bounded spin (about a second), every other wait
+    # sees the fault word within a millisecond and later rows do not wait at all -- the grid drains at once, it does
+    # not give up row by row.  Hundreds of rows depend on the lost one here.
+    import time
+    ctx.sync()
+    ctx.set_option("trsv_tiled", 0)
+    try:
+        ctx.sptrsv(dLs, x, dD, db)
+        ctx.sync()
+        ctx.set_option("trsv_inject_loss", Ls.nnz // 8)
+        t0 = time.perf_counter()
+        ctx.sptrsv(dLs, x, dD, db)
+        with pytest.raises(BisError, match="lost a hand-off"):
+            ctx.sync()
+        assert time.perf_counter() - t0 < 10.0
+        ctx.sptrsv(dLs, x, dD, db)
+        assert np.array_equal(x.to_host(), want)
+    finally:
+        ctx.set_option("trsv_tiled", -1)
+
+
+@pytest.mark.parametrize("kind", ["j", "gs", "sgs"])
+@pytest.mark.parametrize("mat", ["hpcg10", "anderson9", "hpcg24"])
+def test_stationary_device_schedules(ctx, oracle, kind, mat):
+    """bis_stat_*: Jacobi / GS / SGS with the iteration, the true residual of every iterate, its norm and the
+    stopping test on the device (jacobi.hpp:43-52,:102-107; gauss_seidel.hpp:26-52,:99-104; solver.hpp:177-192).
+    Against the same iteration made kernel by kernel through the C ABI with a blocking norm (the reference's
+    schedule): sampled norms bit-identical, same stopping iteration, same iterate; against the oracle's solver:
+    history within 1e-10 r0, same iteration count; launches enqueued behind the stopping iteration change nothing."""
+    A = {"hpcg10": lambda: oracle.gen_hpcg(10), "anderson9": lambda: oracle.gen_anderson(9, shift=9.0), "hpcg24": lambda: oracle.gen_hpcg(24)}[mat]()
+    dA = {"hpcg10": lambda: ctx.gen_hpcg(10), "anderson9": lambda: ctx.gen_anderson(9, shift=9.0), "hpcg24": lambda: ctx.gen_hpcg(24)}[mat]()
+    n = A.n_rows
+    tol, max_iters = 1e-14, 400
+    dLs, dUs, dD, dDinv = ctx.split_strict(dA)
+    b = ctx.upload(np.full(n, 1.0))
+    # the kernel-by-kernel schedule
+    x, xn, t, r = ctx.upload(np.full(n, 0.1)), ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    ctx.compute_residual(dA, x, b, r, t)
+    hist = [ctx.euclidean_vec_norm(r)]
+    for it in range(max_iters):
+        if kind == "j":
+            ctx.spmv(dA, x, xn)
+            ctx.normalize_x(xn, x, dD, b)
+            x, xn = xn, x
+        else:
+            ctx.spmv(dUs, x, t); ctx.subtract_vectors(t, b, t); ctx.sptrsv(dLs, x, dD, t)
+            if kind == "sgs":
+                ctx.spmv(dLs, x, t); ctx.subtract_vectors(t, b, t); ctx.bsptrsv(dUs, x, dD, t)
+        ctx.compute_residual(dA, x, b, r, t)
+        hist.append(ctx.euclidean_vec_norm(r))
+        if hist[-1] < tol * hist[0] or not np.isfinite(hist[-1]):
+            break
+    hist = np.array(hist)
+    x_sep = x.to_host()
+    # the device schedule, enqueued in one go and well past the stopping iteration
+    y = ctx.upload(np.full(n, 0.1))
+    st = ctx.stat(kind, dA, dD, b, y, dLs, dUs)
+    r0 = st.init(tol)
+    st.iterate(7)
+    st.iterate(max_iters - 7)
+    iters, conv, h2 = st.status(hist_cap=1024)
+    out = ctx.alloc(n)
+    st.solution(out)
+    if conv:  # launches behind the stopping iteration are no-ops
+        st.iterate(25)
+        it3, conv3, h3 = st.status(hist_cap=1024)
+        out3 = ctx.alloc(n)
+        st.solution(out3)
+        assert it3 == iters and conv3 and np.array_equal(h3, h2) and np.array_equal(out3.to_host(), out.to_host())
+    assert r0 == hist[0] and iters == len(hist) - 1 and conv == (hist[-1] < tol * hist[0])
+    assert np.array_equal(h2, hist)
+    assert np.array_equal(out.to_host(), x_sep)
+    ref = oracle.solve(A, kind, "none", max_iters=max_iters, tol=tol)
+    m = min(len(ref["hist"]), len(h2))
+    assert np.max(np.abs(ref["hist"][:m] - h2[:m])) <= 1e-10 * ref["hist"][0]
+    if conv:
+        assert abs(iters - ref["iters"]) <= 1
+    st.free()
+
+
+def test_sweep_plans_follow_values_changed_in_place(ctx, oracle):
+    """The tiled sweep's plan holds a copy of the triangle's values in its entry stream, row views of the level plans
+    hold dictionaries: after the values change in place (written through bis_mat_debug_ptrs, then bis_mat_retune --
+    bis_mat_scale_sym takes the same path) the next sweep must use the new values, bit-exact against the oracle
+    (kernels.hpp:54-107), with the tiled and with the level-scheduled kernels."""
+    from basic_iterative_solvers_amd import Vec
+    A = oracle.gen_hpcg(20)
+    n = A.n_rows
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    b = np.random.default_rng(21).uniform(-1, 1, n)
+    for tiled in (-1, 0):
+        ctx.set_option("trsv_tiled", tiled)
+        try:
+            dLs, dUs, dD, dDinv = ctx.split_strict(ctx.gen_hpcg(20))
+            db, x = ctx.upload(b), ctx.alloc(n)
+            ctx.sptrsv(dLs, x, dD, db)
+            assert np.array_equal(x.to_host(), oracle.sptrsv(Ls, D, b))
+            new_val = Ls.val * np.random.default_rng(22).uniform(0.5, 1.5, Ls.nnz)
+            Vec(ctx, dLs.debug_ptrs()[2], Ls.nnz, False).set(new_val)
+            dLs.retune()
+            ctx.sptrsv(dLs, x, dD, db)
+            Ls2 = CRS(n, Ls.row_ptr, Ls.col, new_val)
+            assert np.array_equal(x.to_host(), oracle.sptrsv(Ls2, D, b)), tiled
+        finally:
+            ctx.set_option("trsv_tiled", -1)
 
 
 def test_sptrsv_wave_grid_is_capped_by_residency(ctx, oracle):

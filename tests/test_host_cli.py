@@ -58,6 +58,20 @@ def test_cli_residual_table_vs_reference(key):
         assert r["iters"] == e["iters"]
 
 
+@pytest.mark.parametrize("solver", ["j", "gs", "sgs"])
+@pytest.mark.parametrize("name", ["FDM-2d-16", "matrix_band_klein", "hpcg8", "anderson8_shift9"])
+def test_cli_stationary_device_schedule_equals_unfused(name, solver):
+    """-j / -gs / -sgs run the device schedule (bis_stat_*: norm and stopping test on the device, Jacobi with one
+    SpMV per iteration) by default; -unfused is the reference's kernel-by-kernel order with a blocking norm per
+    iteration (jacobi.hpp:43-52,:102-107; gauss_seidel.hpp:26-52,:99-104).  Same arithmetic per element and per
+    partial sum: the printed residual tables are identical digit for digit, so is the iteration count (also
+    where the solver does not converge: FDM-2d-16 -j runs to MAX_ITERS in the reference)."""
+    a = run_cli(name, solver, "none", {})
+    b = run_cli(name, solver, "none", {}, extra=["-unfused"])
+    assert a["iters"] == b["iters"] and a["converged"] == b["converged"]
+    assert len(a["hist"]) == len(b["hist"]) and np.array_equal(a["hist"], b["hist"])
+
+
 @pytest.mark.parametrize("pc", ["none", "j"])
 def test_cli_fused_and_unfused_cg_agree(pc):
     """The fused device schedule and the reference's kernel-by-kernel order
