@@ -418,7 +418,9 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
     if (n == 0) return BIS_OK;
     const int g = grid_for(n);
     const size_t nblk = cg->dist ? (size_t)bis_dist_total_blocks(cg->dist) : (size_t)cg->A->n_blocks_f;
-    bis_status st = bis_ensure_partials(ctx, std::max((size_t)2 * kMaxReduceBlocks, nblk * 16)); // <= 16 waves per row block
+    size_t need = std::max((size_t)2 * kMaxReduceBlocks, nblk * 16); // <= 16 waves per row block
+    if (!cg->dist) need = std::max(need, (size_t)bis_spmv_sellwin_slices(cg->A)); // sliced-ELL form: one partial per 64 rows
+    bis_status st = bis_ensure_partials(ctx, need);
     if (st != BIS_OK) return st;
     ctx->spmv_stop = cg->flags;
     struct StopGuard { bis_ctx *c; ~StopGuard() { c->spmv_stop = nullptr; } } stop_guard{ctx};

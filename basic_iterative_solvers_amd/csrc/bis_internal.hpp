@@ -85,6 +85,8 @@ struct bis_options {
     int trsv_tile_edge = -1; // grid-hinted matrices: tile extents in nodes, e (cubic) or ex | ey << 8 | ez << 16 (default by row length; 0 = interval tiles of the natural order)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
     int spmv_sellwin = -1; // dictionary SpMV with the block's x window in LDS and sliced-ELL codes (bis_spmv_sell.hip): 0 off (-1: on where the matrix qualifies)
+    int spmv_sellwin_rows = -1; // rows per lane of the sliced-ELL form: 1 or 2 (blocks of 256 or 512 rows; -1: default 2)
+    int spmv_sellwin_joint = -1; // 0: never the 16-bit joint (slot, value) codes
     int device_share = -1;  // k > 1: this device is shared by k processes that all run persistent grids (several ranks on one GPU in a test
                             // or rehearsal): kernels that need their whole grid resident keep to 1/k of the device
     int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes
@@ -284,6 +286,8 @@ bis_status bis_spmv_try_valdict(bis_ctx *ctx, bis_mat *A, bool consecutive_ok);
 bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A);
 int bis_spmv_sellwin_blocks(const bis_mat *A);
 int64_t bis_spmv_sellwin_bytes(const bis_mat *A);
+int64_t bis_spmv_sellwin_slices(const bis_mat *A);
+int bis_spmv_sellwin_format(const bis_mat *A);
 bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y, int mode, const double *w,
                                    double *partials, const int *stop, int remap_arg, int grid);
 void bis_spmv_sellwin_drop(bis_mat *A);

@@ -1207,7 +1207,8 @@ static bis_status launch_sellwin(bis_ctx *ctx, const bis_mat *A, const SpmvArgs 
     if (bis_status st = bis_spmv_sellwin_try(ctx, const_cast<bis_mat *>(A))) return st;
     const int nbr = bis_spmv_sellwin_blocks(A);
     if (!nbr) return BIS_OK;
-    if (mode == 1 && partials_off + (size_t)nbr * 4 > ctx->partials_cap) {
+    const int64_t n_slices = bis_spmv_sellwin_slices(A); // one partial of the fused dot per 64-row slice
+    if (mode == 1 && partials_off + (size_t)n_slices > ctx->partials_cap) {
         ctx->err = "bis_spmv: partials buffer too small (internal)";
         return BIS_ERR_INVALID;
     }
@@ -1217,7 +1218,7 @@ static bis_status launch_sellwin(bis_ctx *ctx, const bis_mat *A, const SpmvArgs 
                                             remap_arg, grid_for_map(nbr, remap_arg));
     bis_prof_end(ctx);
     if (st != BIS_OK) return st;
-    if (mode == 1 && n_partials) *n_partials = nbr * 4;
+    if (mode == 1 && n_partials) *n_partials = (int)n_slices;
     *done = true;
     return BIS_OK;
 }
@@ -1389,7 +1390,7 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
     }
     if (!f && a.vcode && !a.vd_rm_only && spmv_variant(a) == 20 && a.pk_mode == 1) f = 1;
     if (col_bytes) *col_bytes = (f >= 2 || a.pk_mode) ? 2 : 4;
-    if (val_bytes) *val_bytes = f ? 1 : 8;
+    if (val_bytes) *val_bytes = f ? (f >= 4 && bis_spmv_sellwin_format(A) == 2 ? 0 : 1) : 8; // 0: the value index shares the 16-bit column code
     if (n_dict) *n_dict = f ? A->vd_n : 0;
     if (form) *form = f;
     return BIS_OK;

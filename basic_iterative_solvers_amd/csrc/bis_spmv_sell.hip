@@ -11,6 +11,11 @@
 //   * sliced ELL: the codes of a slice (64 consecutive rows = one wave) are stored chunk-major -- chunk c holds
 //     entries 4c..4c+3 of every row of the slice, 12 bytes per lane (4 x 16-bit column code, 4 x 8-bit value code)
 //     -- so a lane loads its own codes with one coalesced 12-byte load per 4 non-zeros: no staging, no row_ptr.
+//     Where the table (dictionary + padding value [+ the per-row-diagonal marker]) has at most 8 entries -- every
+//     constant-coefficient stencil -- a non-zero is ONE 16-bit code, window slot : 13 | table index : 3, 8 bytes per
+//     lane and chunk: 2 streamed bytes per non-zero.
+//   * a block is 256 R rows (R = 1, 2, 4 rows per lane, one 64-row slice after the other): the larger R, the fewer
+//     times an x entry is copied into some block's window (HPCG: 9 x at R = 1, 6 x at R = 2), at a larger window.
 //     A slice has as many chunks as its longest row needs; shorter rows are padded with an entry that is neutral in
 //     IEEE arithmetic whatever the accumulator holds: value 1.0 times an LDS slot holding -0.0 (acc + -0.0 == acc
 //     for every acc, including -0.0, infinities and NaN).
@@ -31,10 +36,12 @@ struct bis_sellwin {
     int64_t n_slices = 0, total_chunks = 0;
     int32_t *hdr = nullptr;          // [n_blocks * 64]: words 0..31 first granule of run k, words 32..63 (rank of the run's first granule in the window) | (granules << 16)
     int64_t *slice_chunk0 = nullptr; // [n_slices + 1]
-    uint32_t *codes = nullptr;       // [total_chunks * 64 * 3]
+    uint32_t *codes = nullptr;       // [(total_chunks + 1) * 64 * (fmt == 2 ? 2 : 3)]
     double *dict = nullptr;          // [256] the matrix' dictionary plus the padding value 1.0
     int max_gran = 0;                // largest window of a block, in granules
-    bool small = false;              // <= 32 table entries: the value byte holds 8 * index
+    int fmt = 0;                     // 0: 12-byte chunks, value byte = table index; 1: value byte = 8 * index (<= 32 entries);
+                                     // 2: 8-byte chunks, 16-bit codes slot : 13 | index : 3 (<= 8 entries)
+    int R = 1;                       // rows per lane: a block is 256 R rows
     bool diag = false;               // one value code stands for the row's own diagonal value (vdiag)
     int pad_idx = 0, diag_idx = 0;
 };
@@ -45,7 +52,10 @@ constexpr int kSwRows = 256;
 constexpr int kSwRuns = 32;
 constexpr int kSwRunGran = 64; // granules per run at most
 constexpr int kSwHash = 4096;
-constexpr int kSwMaxGran = 940; // window <= (2 + 8 * 940) * 8 = 60176 bytes; with the tables in front of it < 64 KiB
+constexpr int kSwMaxGran = 940; // window <= (2 + 8 * 940) * 8 = 60176 bytes (list[1024] in the plan kernel, 13-bit slots in the joint codes)
+constexpr int kSwDefaultR = 2;
+// ... and with the tables in front of it the workgroup stays within 64 KiB of LDS
+inline int sw_gran_cap(int R) { return std::min(kSwMaxGran, (65536 - (2048 + 2048 * R) - 16) / 64); }
 
 __device__ __forceinline__ int sw_wave_max(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
@@ -56,23 +66,24 @@ __device__ __forceinline__ int sw_wave_max(int v) {
 // into runs of consecutive granules; chunks per slice.  status[0] = 1: not representable; status[1] = max granules.
 template <typename RP>
 __global__ __launch_bounds__(256) void sw_plan_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
-                                                      int64_t n_rows, int32_t *__restrict__ hdr,
+                                                      int64_t n_rows, int R, int max_gran, int32_t *__restrict__ hdr,
                                                       int32_t *__restrict__ slice_chunks, int *status) {
     __shared__ int table[kSwHash];
     __shared__ int list[1024];
     __shared__ int cnt, n_runs, failed;
     __shared__ int run_g0[kSwRuns], run_rank[kSwRuns], srt_g0[kSwRuns], srt_rank[kSwRuns + 1];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int64_t r0 = (int64_t)b * kSwRows;
-    const int rows = (int)min((int64_t)kSwRows, n_rows - r0);
+    const int64_t r0 = (int64_t)b * kSwRows * R;
+    const int rows = (int)min((int64_t)kSwRows * R, n_rows - r0);
     for (int i = tid; i < kSwHash; i += 256) table[i] = -1;
     if (tid == 0) { cnt = 0; n_runs = 0; failed = 0; }
     __syncthreads();
-    {
+    for (int r = 0; r < R; ++r) { // wave w owns the R consecutive slices w R .. w R + R - 1 of the block
+        const int sl = (tid >> 6) * R + r, lr = sl * 64 + (tid & 63);
         int len = 0;
-        if (tid < rows) len = (int)((int64_t)row_ptr[r0 + tid + 1] - (int64_t)row_ptr[r0 + tid]);
+        if (lr < rows) len = (int)((int64_t)row_ptr[r0 + lr + 1] - (int64_t)row_ptr[r0 + lr]);
         const int m = sw_wave_max(len);
-        if ((tid & 63) == 0) slice_chunks[(size_t)b * 4 + (tid >> 6)] = (m + 3) >> 2;
+        if ((tid & 63) == 0) slice_chunks[(size_t)b * 4 * R + sl] = (m + 3) >> 2;
     }
     const int64_t s = (int64_t)row_ptr[r0], e = (int64_t)row_ptr[r0 + rows];
     for (int64_t k = s + tid; k < e; k += 256) {
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(256) void sw_plan_kernel(const RP *__restrict__ row
             if (cur == -1) {
                 const int old = atomicCAS(&table[h], -1, g);
                 if (old == -1) {
-                    if (atomicAdd(&cnt, 1) >= kSwMaxGran) atomicExch(&failed, 1);
+                    if (atomicAdd(&cnt, 1) >= max_gran) atomicExch(&failed, 1);
                     break;
                 }
                 if (old == g) break;
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void sw_plan_kernel(const RP *__restrict__ row
     }
     __syncthreads();
     const int n = cnt;
-    if (failed || n > kSwMaxGran) {
+    if (failed || n > max_gran) {
         if (tid == 0) atomicExch(&status[0], 1);
         return;
     }
@@ -175,10 +186,10 @@ __global__ __launch_bounds__(256) void sw_widen_kernel(const int32_t *__restrict
     if (i < n) out[i] = in[i];
 }
 
-// One workgroup per block: a lane writes the chunks of its row.
-template <typename RP, bool SMALL>
+// One workgroup per block: a lane writes the chunks of its R rows.
+template <typename RP>
 __global__ __launch_bounds__(256) void sw_fill_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
-                                                      const uint8_t *__restrict__ vcode, int64_t vd_base, int64_t n_rows,
+                                                      const uint8_t *__restrict__ vcode, int64_t vd_base, int64_t n_rows, int R, int fmt,
                                                       const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
                                                       uint32_t *__restrict__ codes, int pad_idx, int diag_idx) {
     __shared__ int g0s[kSwRuns], rk[kSwRuns];
@@ -193,86 +204,103 @@ __global__ __launch_bounds__(256) void sw_fill_kernel(const RP *__restrict__ row
     }
     __syncthreads();
     const int nr = nr_s;
-    const int64_t r = (int64_t)b * kSwRows + tid;
-    int64_t rs = 0;
-    int len = 0;
-    if (r < n_rows) {
-        rs = (int64_t)row_ptr[r];
-        len = (int)((int64_t)row_ptr[r + 1] - rs);
-    }
-    const int64_t slice = (int64_t)b * 4 + wv;
-    const int64_t c0 = slice_chunk0[slice];
-    const int nch = (int)(slice_chunk0[slice + 1] - c0);
-    const unsigned pad_byte = SMALL ? (unsigned)pad_idx * 8u : (unsigned)pad_idx;
-    for (int c = 0; c < nch; ++c) {
-        unsigned cc[4], vv[4];
+    const int words = fmt == 2 ? 2 : 3;
+    for (int rr = 0; rr < R; ++rr) {
+        const int64_t slice = ((int64_t)b * 4 + wv) * R + rr;
+        const int64_t r = slice * 64 + lane;
+        int64_t rs = 0;
+        int len = 0;
+        if (r < n_rows) {
+            rs = (int64_t)row_ptr[r];
+            len = (int)((int64_t)row_ptr[r + 1] - rs);
+        }
+        const int64_t c0 = slice_chunk0[slice];
+        const int nch = (int)(slice_chunk0[slice + 1] - c0);
+        for (int c = 0; c < nch; ++c) {
+            unsigned cc[4], vv[4]; // window slot, table index
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = 4 * c + q;
-            cc[q] = 0;
-            vv[q] = pad_byte;
-            if (j < len) {
-                const int ci = col[rs + j];
-                const int g = ci >> 3;
-                int lo = 0, hi = nr - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (g0s[mid] <= g) lo = mid; else hi = mid - 1;
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * c + q;
+                cc[q] = 0;
+                vv[q] = (unsigned)pad_idx;
+                if (j < len) {
+                    const int ci = col[rs + j];
+                    const int g = ci >> 3;
+                    int lo = 0, hi = nr - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (g0s[mid] <= g) lo = mid; else hi = mid - 1;
+                    }
+                    cc[q] = (unsigned)(2 + (rk[lo] + (g - g0s[lo])) * 8 + (ci & 7));
+                    const unsigned vb = vcode[rs + j - vd_base];
+                    vv[q] = vb == 255u && diag_idx >= 0 ? (unsigned)diag_idx : vb;
                 }
-                const int slot = 2 + (rk[lo] + (g - g0s[lo])) * 8 + (ci & 7);
-                cc[q] = (unsigned)slot * 8u;
-                const unsigned vb = vcode[rs + j - vd_base];
-                vv[q] = SMALL ? (vb == 255u ? (unsigned)diag_idx * 8u : vb * 8u) : vb;
+            }
+            uint32_t *dst = codes + ((size_t)(c0 + c) * 64 + lane) * words;
+            if (fmt == 2) { // slot : 13 | index : 3
+                dst[0] = (cc[0] << 3 | vv[0]) | (cc[1] << 3 | vv[1]) << 16;
+                dst[1] = (cc[2] << 3 | vv[2]) | (cc[3] << 3 | vv[3]) << 16;
+            } else { // byte offsets of the slots, then the value bytes (fmt 1: 8 * index)
+                const unsigned sh = fmt == 1 ? 3 : 0;
+                dst[0] = (cc[0] * 8u) | (cc[1] * 8u) << 16;
+                dst[1] = (cc[2] * 8u) | (cc[3] * 8u) << 16;
+                dst[2] = (vv[0] << sh) | (vv[1] << sh) << 8 | (vv[2] << sh) << 16 | (vv[3] << sh) << 24;
             }
         }
-        uint32_t *dst = codes + ((size_t)(c0 + c) * 64 + lane) * 3;
-        dst[0] = cc[0] | (cc[1] << 16);
-        dst[1] = cc[2] | (cc[3] << 16);
-        dst[2] = vv[0] | (vv[1] << 8) | (vv[2] << 16) | (vv[3] << 24);
     }
 }
 
-struct sw_chunk { uint32_t a, b, c; };
+template <int FMT> struct sw_chunk { uint32_t a, b, c; };
+template <> struct sw_chunk<2> { uint32_t a, b; };
 
-template <bool DIAG, bool SMALL>
+template <bool DIAG, int FMT, int R>
 struct SwLayout {
-    static constexpr int kDictBytes = SMALL ? 256 : 2048;
+    static constexpr int kDictBytes = FMT == 2 ? 64 : (FMT == 1 ? 256 : 2048);
     static constexpr int kDiagOff = kDictBytes;
-    static constexpr int kWinOff = kDictBytes + (DIAG ? 2048 : 0);
-    static constexpr unsigned kDiagByte = SMALL ? 248u : 255u;
+    static constexpr int kWinOff = kDictBytes + (DIAG ? 2048 * R : 0);
+    static constexpr unsigned kDiagCode = FMT == 2 ? 7u : (FMT == 1 ? 248u : 255u); // the value code that stands for the row's diagonal
 };
 
-// four non-zeros of every row of the wave: acc += dict[value code] * window[column code], in entry order
-template <bool DIAG, bool SMALL>
-__device__ __forceinline__ void sw_chunk_fma(const unsigned char *lds, const sw_chunk &cd, unsigned diag_rel, double &acc) {
+// four non-zeros of every row of the wave: acc += table[value code] * window[column code], in entry order
+template <bool DIAG, int FMT, int R>
+__device__ __forceinline__ void sw_chunk_fma(const unsigned char *lds, const sw_chunk<FMT> &cd, unsigned diag_rel, double &acc) {
 #pragma clang fp contract(off)
-    using L = SwLayout<DIAG, SMALL>;
-    const unsigned xa[4] = {cd.a & 0xffffu, cd.a >> 16, cd.b & 0xffffu, cd.b >> 16};
+    using L = SwLayout<DIAG, FMT, R>;
+    const unsigned code[4] = {cd.a & 0xffffu, cd.a >> 16, cd.b & 0xffffu, cd.b >> 16};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const unsigned vb = (cd.c >> (8 * q)) & 0xffu;
-        unsigned va = SMALL ? vb : vb << 3;
-        if (DIAG) va = vb == L::kDiagByte ? diag_rel : va;
-        const double xv = *reinterpret_cast<const double *>(lds + L::kWinOff + xa[q]);
+        unsigned xa, vc, va;
+        if constexpr (FMT == 2) {
+            xa = code[q] & 0xfff8u;
+            vc = code[q] & 7u;
+            va = vc << 3;
+        } else {
+            xa = code[q];
+            vc = (cd.c >> (8 * q)) & 0xffu;
+            va = FMT == 1 ? vc : vc << 3;
+        }
+        if (DIAG) va = vc == L::kDiagCode ? diag_rel : va;
+        const double xv = *reinterpret_cast<const double *>(lds + L::kWinOff + xa);
         const double v = *reinterpret_cast<const double *>(lds + va);
         const double pr = v * xv;
         acc = acc + pr;
     }
 }
 
-template <int Q, bool DIAG, bool SMALL>
-__device__ __forceinline__ void sw_consume(const unsigned char *lds, const sw_chunk (&cd)[8], unsigned diag_rel, double &acc) {
+template <int Q, bool DIAG, int FMT, int R>
+__device__ __forceinline__ void sw_consume(const unsigned char *lds, const sw_chunk<FMT> (&cd)[8], unsigned diag_rel, double &acc) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) sw_chunk_fma<DIAG, SMALL>(lds, cd[q], diag_rel, acc);
+    for (int q = 0; q < Q; ++q) sw_chunk_fma<DIAG, FMT, R>(lds, cd[q], diag_rel, acc);
 }
 
-// MODE 0: y = A x.  MODE 1: also partials[4 b + wave] = sum over the wave's rows of y[r] w[r] (CG's (Ap, p)).
-template <int MODE, bool DIAG, bool SMALL>
+// MODE 0: y = A x.  MODE 1: also partials[slice] = sum over the slice's rows of y[r] w[r] (CG's (Ap, p)).
+template <int MODE, bool DIAG, int FMT, int R>
 __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
     double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
     const uint32_t *__restrict__ codes, const double *__restrict__ dict_g, const double *__restrict__ vdiag, int x_al16) {
-    using L = SwLayout<DIAG, SMALL>;
+    using L = SwLayout<DIAG, FMT, R>;
+    using Chunk = sw_chunk<FMT>;
     if (stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int b = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
@@ -281,22 +309,30 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hw = hdr[(size_t)b * 64 + lane];
-    const int64_t slice = (int64_t)b * 4 + wv;
-    const int64_t c0 = slice_chunk0[slice];
-    const int nch = (int)(slice_chunk0[slice + 1] - c0);
-    const sw_chunk *cp = reinterpret_cast<const sw_chunk *>(codes) + (size_t)c0 * 64 + lane;
-    sw_chunk cd[8];
-    {
-        const int last = max(nch - 1, 0); // (the stream ends with one spare chunk: an empty last slice reads it)
+    const int64_t slice0 = ((int64_t)b * 4 + wv) * R; // this wave's R consecutive slices
+    int64_t c0[R];
+    int nch[R];
+    Chunk cd[R][8];
+    double wr[R], dval[R];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) cd[q] = cp[(size_t)min(q, last) * 64];
+    for (int r = 0; r < R; ++r) {
+        c0[r] = slice_chunk0[slice0 + r];
+        nch[r] = (int)(slice_chunk0[slice0 + r + 1] - c0[r]);
+        const Chunk *cp = reinterpret_cast<const Chunk *>(codes) + (size_t)c0[r] * 64 + lane;
+        const int last = max(nch[r] - 1, 0); // (the stream ends with one spare chunk: an empty last slice reads it)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cd[r][q] = cp[(size_t)min(q, last) * 64];
+        const int64_t row = (slice0 + r) * 64 + lane;
+        wr[r] = 0.0;
+        if (MODE == 1 && row < n_rows) wr[r] = w[row];
+        if (DIAG) dval[r] = row < n_rows ? vdiag[row] : 0.0;
     }
-    const int64_t row = (int64_t)b * kSwRows + tid;
-    double wr = 0.0;
-    if (MODE == 1 && row < n_rows) wr = w[row];
     // tables
     if (tid < L::kDictBytes / 8) reinterpret_cast<double *>(lds)[tid] = dict_g[tid];
-    if (DIAG) reinterpret_cast<double *>(lds + L::kDiagOff)[tid] = row < n_rows ? vdiag[row] : 0.0;
+    if (DIAG) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) reinterpret_cast<double *>(lds + L::kDiagOff)[(wv * R + r) * 64 + lane] = dval[r];
+    }
     if (tid == 0) *reinterpret_cast<double *>(lds + L::kWinOff) = -0.0;
     // window: the runs of 8-column granules; a run has at most 256 pieces of 16 bytes, a wave takes 64 of them and
     // the hardware writes them to LDS behind the wave-uniform base (no register staging, nothing waited for here)
@@ -325,29 +361,34 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
         }
     }
     __syncthreads();
-    const unsigned diag_rel = (unsigned)(L::kDiagOff + tid * 8);
-    double acc = 0.0;
-    for (int cb = 0; cb < nch; cb += 8) {
-        const int rem = nch - cb;
-        if (cb > 0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) cd[q] = cp[(size_t)(cb + min(q, rem - 1)) * 64];
+    for (int r = 0; r < R; ++r) {
+        const unsigned diag_rel = (unsigned)(L::kDiagOff + ((wv * R + r) * 64 + lane) * 8);
+        const Chunk *cp = reinterpret_cast<const Chunk *>(codes) + (size_t)c0[r] * 64 + lane;
+        double acc = 0.0;
+        for (int cb = 0; cb < nch[r]; cb += 8) {
+            const int rem = nch[r] - cb;
+            if (cb > 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cd[r][q] = cp[(size_t)(cb + min(q, rem - 1)) * 64];
+            }
+            switch (rem) {
+            case 1: sw_consume<1, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            case 2: sw_consume<2, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            case 3: sw_consume<3, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            case 4: sw_consume<4, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            case 5: sw_consume<5, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            case 6: sw_consume<6, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            case 7: sw_consume<7, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            default: sw_consume<8, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            }
         }
-        switch (rem) {
-        case 1: sw_consume<1, DIAG, SMALL>(lds, cd, diag_rel, acc); break;
-        case 2: sw_consume<2, DIAG, SMALL>(lds, cd, diag_rel, acc); break;
-        case 3: sw_consume<3, DIAG, SMALL>(lds, cd, diag_rel, acc); break;
-        case 4: sw_consume<4, DIAG, SMALL>(lds, cd, diag_rel, acc); break;
-        case 5: sw_consume<5, DIAG, SMALL>(lds, cd, diag_rel, acc); break;
-        case 6: sw_consume<6, DIAG, SMALL>(lds, cd, diag_rel, acc); break;
-        case 7: sw_consume<7, DIAG, SMALL>(lds, cd, diag_rel, acc); break;
-        default: sw_consume<8, DIAG, SMALL>(lds, cd, diag_rel, acc); break;
+        const int64_t row = (slice0 + r) * 64 + lane;
+        if (row < n_rows) y[row] = acc;
+        if (MODE == 1) {
+            const double t = wave_sum(row < n_rows ? acc * wr[r] : 0.0);
+            if (lane == 0) partials[slice0 + r] = t;
         }
-    }
-    if (row < n_rows) y[row] = acc;
-    if (MODE == 1) {
-        const double t = wave_sum(row < n_rows ? acc * wr : 0.0);
-        if (lane == 0) partials[(size_t)b * 4 + wv] = t;
     }
 }
 
@@ -383,8 +424,11 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     if (A->sw_state != 0) return BIS_OK;
     A->sw_state = -1;
     if (!sw_enabled() || A->vd_state != 1 || A->n_rows == 0 || A->nnz == 0 || A->n_cols >= ((int64_t)1 << 31) - 16) return BIS_OK;
-    const int64_t nb64 = (A->n_rows + kSwRows - 1) / kSwRows;
-    if (nb64 > (int64_t)1 << 28) return BIS_OK;
+    int R = kSwDefaultR;
+    while (R > 1 && A->n_rows < (int64_t)kSwRows * R * 1024) R >>= 1; // small matrices: more, smaller blocks
+    if (bis_opts().spmv_sellwin_rows > 0) R = bis_opts().spmv_sellwin_rows >= 2 ? 2 : 1;
+    const int64_t nb64 = (A->n_rows + (int64_t)kSwRows * R - 1) / ((int64_t)kSwRows * R);
+    if (nb64 > (int64_t)1 << 26) return BIS_OK;
     const int nb = (int)nb64;
     // the table: the matrix' dictionary and the padding value 1.0
     double table[256];
@@ -403,11 +447,14 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     bis_sellwin *sw = new bis_sellwin;
     A->sw = sw;
     sw->n_blocks = nb;
-    sw->n_slices = (int64_t)nb * 4;
-    sw->small = n_tab <= cap_small;
+    sw->R = R;
+    sw->n_slices = (int64_t)nb * 4 * R;
     sw->diag = A->vd_diag;
+    // 16-bit joint codes where the table (+ the diagonal marker 7) fits 3 bits; else value bytes
+    const bool joint = n_tab <= (A->vd_diag ? 7 : 8) && bis_opts().spmv_sellwin_joint != 0;
+    sw->fmt = joint ? 2 : (n_tab <= cap_small ? 1 : 0);
     sw->pad_idx = pad_idx;
-    sw->diag_idx = 31;
+    sw->diag_idx = !A->vd_diag ? -1 : (sw->fmt == 2 ? 7 : (sw->fmt == 1 ? 31 : 255));
     int32_t *slice_chunks = nullptr;
     void *tmp = nullptr;
     int *status = (int *)ctx->counters + 52;
@@ -418,8 +465,8 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     SW_CHECK(hipMemcpyAsync(sw->dict, table, sizeof table, hipMemcpyHostToDevice, ctx->stream));
     SW_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream));
     SW_CHECK(hipMemsetAsync(slice_chunks + sw->n_slices, 0, sizeof(int32_t), ctx->stream));
-    if (A->rp64) hipLaunchKernelGGL(sw_plan_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->n_rows, sw->hdr, slice_chunks, status);
-    else hipLaunchKernelGGL(sw_plan_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->n_rows, sw->hdr, slice_chunks, status);
+    if (A->rp64) hipLaunchKernelGGL(sw_plan_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->n_rows, R, sw_gran_cap(R), sw->hdr, slice_chunks, status);
+    else hipLaunchKernelGGL(sw_plan_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->n_rows, R, sw_gran_cap(R), sw->hdr, slice_chunks, status);
     SW_CHECK(hipGetLastError());
     int h[2] = {0, 0};
     SW_CHECK(hipMemcpyAsync(h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -444,11 +491,11 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
         A->sw_state = -1;
         return BIS_OK;
     }
-    SW_CHECK(hipMalloc(&sw->codes, sizeof(uint32_t) * 3 * 64 * (size_t)(total + 1)));
-    SW_CHECK(hipMemsetAsync(sw->codes + (size_t)total * 192, 0, sizeof(uint32_t) * 192, ctx->stream));
-#define SW_FILL(RP, SMALL) hipLaunchKernelGGL((sw_fill_kernel<RP, SMALL>), dim3(nb), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, sw->hdr, sw->slice_chunk0, sw->codes, sw->pad_idx, sw->diag_idx)
-    if (A->rp64) { if (sw->small) SW_FILL(int64_t, true); else SW_FILL(int64_t, false); }
-    else { if (sw->small) SW_FILL(int32_t, true); else SW_FILL(int32_t, false); }
+    const size_t cw = sw->fmt == 2 ? 128 : 192; // 32-bit words per chunk of 64 lanes
+    SW_CHECK(hipMalloc(&sw->codes, sizeof(uint32_t) * cw * (size_t)(total + 1)));
+    SW_CHECK(hipMemsetAsync(sw->codes + (size_t)total * cw, 0, sizeof(uint32_t) * cw, ctx->stream));
+#define SW_FILL(RP) hipLaunchKernelGGL((sw_fill_kernel<RP>), dim3(nb), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, R, sw->fmt, sw->hdr, sw->slice_chunk0, sw->codes, sw->pad_idx, sw->diag_idx)
+    if (A->rp64) SW_FILL(int64_t); else SW_FILL(int32_t);
 #undef SW_FILL
     SW_CHECK(hipGetLastError());
     A->sw_state = 1;
@@ -456,11 +503,13 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
 }
 
 int bis_spmv_sellwin_blocks(const bis_mat *A) { return A->sw_state == 1 ? A->sw->n_blocks : 0; }
+int64_t bis_spmv_sellwin_slices(const bis_mat *A) { return A->sw_state == 1 ? A->sw->n_slices : 0; }
+int bis_spmv_sellwin_format(const bis_mat *A) { return A->sw_state == 1 ? A->sw->fmt : -1; }
 
 // bytes of the form's own arrays one launch reads: the code stream (with its padding), block headers, slice offsets, table
 int64_t bis_spmv_sellwin_bytes(const bis_mat *A) {
     if (A->sw_state != 1) return 0;
-    return A->sw->total_chunks * 768 + (int64_t)A->sw->n_blocks * 256 + 8 * (A->sw->n_slices + 1) + 2048;
+    return A->sw->total_chunks * (A->sw->fmt == 2 ? 512 : 768) + (int64_t)A->sw->n_blocks * 256 + 8 * (A->sw->n_slices + 1) + 2048;
 }
 
 // mode 0 / 1 as in the kernel; grid and remap_arg from the caller's block map over bis_spmv_sellwin_blocks(A)
@@ -469,16 +518,18 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
     const bis_sellwin *sw = A->sw;
     const int x_al16 = ((uintptr_t)x & 15) == 0;
     const size_t win = (size_t)(2 + 8 * sw->max_gran) * 8;
-#define SW_L3(MODE, DIAG, SMALL)                                                                                       \
-    hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, SMALL>), dim3(grid), dim3(256), (SwLayout<DIAG, SMALL>::kWinOff) + win, \
+#define SW_L4(MODE, DIAG, FMT, RR)                                                                                     \
+    hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, FMT, RR>), dim3(grid), dim3(256), (SwLayout<DIAG, FMT, RR>::kWinOff) + win, \
                        ctx->stream, x, y, A->n_rows, A->n_cols, sw->n_blocks, remap_arg, w, partials, stop, sw->hdr,   \
                        sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16)
-#define SW_L2(MODE, DIAG) do { if (sw->small) SW_L3(MODE, DIAG, true); else SW_L3(MODE, DIAG, false); } while (0)
+#define SW_L3(MODE, DIAG, FMT) do { if (sw->R == 2) SW_L4(MODE, DIAG, FMT, 2); else SW_L4(MODE, DIAG, FMT, 1); } while (0)
+#define SW_L2(MODE, DIAG) do { if (sw->fmt == 2) SW_L3(MODE, DIAG, 2); else if (sw->fmt == 1) SW_L3(MODE, DIAG, 1); else SW_L3(MODE, DIAG, 0); } while (0)
 #define SW_L1(MODE) do { if (sw->diag) SW_L2(MODE, true); else SW_L2(MODE, false); } while (0)
     if (mode == 1) SW_L1(1); else SW_L1(0);
 #undef SW_L1
 #undef SW_L2
 #undef SW_L3
+#undef SW_L4
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
 }

@@ -367,7 +367,7 @@ def main():
     }
     cg.free()
     import numpy as np
-    if roof["spmv_stream"]["val_bytes"] == 1:
+    if roof["spmv_stream"]["val_bytes"] < 8:
         # SURVEY 8d's "CRS SpMV": the same loop on the same arrays with the 8-byte CRS values streamed
         leg = cg_leg(ctx, A, b, x, D, min(args.steps, 50), min(args.warmup, 5), args.traffic_json, n1, valdict=0)
         h2 = np.array(leg.pop("residual_history"))

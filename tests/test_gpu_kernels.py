@@ -1273,17 +1273,21 @@ def _banded_few_values(rng, n, n_values, offsets, max_len, ragged=4, empty_every
     return CRS(n, rp, col, val, n_cols=n_cols)
 
 
-@pytest.mark.parametrize("rp64", [0, 1])
-def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64):
+@pytest.mark.parametrize("rp64,rows,joint", [(0, 1, -1), (1, 2, -1), (0, 2, 0), (1, 1, 0)])
+def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint):
     """Forms 4 / 5 of the dictionary SpMV (bis_spmv_sell.hip): the block's x entries in an LDS window, the codes per
     64-row slice in lane order with neutral padding.  y is BIT-IDENTICAL to the kernel that streams the CRS values and
     within the kernel tolerance of the oracle (kernels.hpp:22-42): stencils, banded matrices with several column runs,
     ragged and empty rows, -0.0 / denormal / huge values and -0.0 row sums (the padding must not turn them into +0.0),
     dictionaries of <= 32 and of up to 255 values, the per-row diagonal form, odd sizes (a window granule that reaches
-    past the last column), an x that is only 8-byte aligned, 64-bit row pointers; matrices that do not qualify (256
-    values: no free code for the padding; scattered columns; mostly-padding rows) keep the gather forms."""
+    past the last column), an x that is only 8-byte aligned, 64-bit row pointers; blocks of 256 and of 512 rows
+    (option spmv_sellwin_rows); the 16-bit joint codes (tables of at most 8 entries) and the 12-byte chunks in their
+    place (spmv_sellwin_joint 0); matrices that do not qualify (256 values: no free code for the padding; scattered
+    columns; mostly-padding rows) keep the gather forms."""
     rng = np.random.default_rng(90 + rp64)
     ctx.set_option("force_rp64", rp64)
+    ctx.set_option("spmv_sellwin_rows", rows)
+    ctx.set_option("spmv_sellwin_joint", joint)
     offs_band = np.arange(-40, 41)
     offs_runs = np.concatenate([np.arange(-3, 4), np.arange(-3, 4) + 700, np.arange(-3, 4) - 700, np.arange(-3, 4) + 5000, np.arange(-3, 4) - 5000])
     neg0 = CRS(300, np.arange(0, 301 * 3, 3), np.repeat(np.arange(300), 3).astype(np.int32), np.tile([-0.0, 0.0, -0.0], 300))
@@ -1317,6 +1321,9 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64):
                 info = dA.spmv_stream_info()
                 if mode == -1 and want is not None:
                     assert info[3] == want, (name, info)
+                    if want >= 4:  # 2 streamed bytes per non-zero with the joint codes, 3 otherwise
+                        few = A.nnz > 0 and len(np.unique(A.val.view(np.uint64))) <= 6 and joint != 0 and want == 4
+                        assert info[1] in ((0,) if few else (0, 1)), (name, info)
                 if mode == -1 and "random diagonal" in name:
                     assert info[3] in (5, 3, 0), (name, info)
                 dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
@@ -1339,9 +1346,12 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64):
     finally:
         ctx.set_option("spmv_valdict", -1)
         ctx.set_option("force_rp64", -1)
+        ctx.set_option("spmv_sellwin_rows", -1)
+        ctx.set_option("spmv_sellwin_joint", -1)
 
 
-def test_spmv_sellwin_in_fused_cg(ctx, oracle):
+@pytest.mark.parametrize("rows", [1, 2])
+def test_spmv_sellwin_in_fused_cg(ctx, oracle, rows):
     """The fused (Ap, p) epilogue of form 4 sums over the same 256-row blocks and waves as the lane-per-row gather
     form: the CG history is bit-identical to it, and within 1e-10 r0 of the oracle's (methods/cg.hpp:6-54);
     in-place scaling drops the form and the next SpMV rebuilds it from the new values."""
@@ -1349,6 +1359,7 @@ def test_spmv_sellwin_in_fused_cg(ctx, oracle):
     A = oracle.gen_hpcg(n1)
     n = A.n_rows
     hists = {}
+    ctx.set_option("spmv_sellwin_rows", rows)
     try:
         for sw in (0, -1):
             ctx.set_option("spmv_sellwin", sw)
@@ -1379,6 +1390,7 @@ def test_spmv_sellwin_in_fused_cg(ctx, oracle):
         assert np.max(np.abs(dy.to_host() - oracle.spmv(B, xh))) <= KTOL * np.abs(B.to_scipy()).dot(np.abs(xh)).max()
     finally:
         ctx.set_option("spmv_sellwin", -1)
+        ctx.set_option("spmv_sellwin_rows", -1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 777, 4096, 100001, 1 << 20])

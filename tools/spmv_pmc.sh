@@ -1,7 +1,9 @@
 # Counter passes for the SpMV kernel (one group per run, never combined with trace domains; the program itself follows `--`).
-#   bash tools/spmv_pmc.sh <tag> [valdict]   -> gpurun_out/spmv_pmc_<tag>/
+#   bash tools/spmv_pmc.sh <tag> [valdict] [hpcg|anderson|fem] [size]   -> gpurun_out/spmv_pmc_<tag>/
 TAG=$1
 VD=${2:--1}
+KIND=${3:-hpcg}
+SIZE=${4:-256}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/spmv_pmc_$TAG
 mkdir -p $O
@@ -18,16 +20,21 @@ GROUPS_=(
  "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum"
  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
 )
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r -- python3 $R/tools/spmv_probe.py hpcg 256 20 $VD > $O/trace.log 2>&1 || echo "trace failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r -- python3 $R/tools/spmv_probe.py $KIND $SIZE 20 $VD > $O/trace.log 2>&1 || echo "trace failed"
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 rm -rf $O/trace
 g=0
 for grp in "${GROUPS_[@]}"; do
   g=$((g+1))
-  timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/g$g -o r -- python3 $R/tools/spmv_probe.py hpcg 256 20 $VD > $O/g$g.log 2>&1 || echo "pmc group $g failed: $grp"
+  timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/g$g -o r -- python3 $R/tools/spmv_probe.py $KIND $SIZE 20 $VD > $O/g$g.log 2>&1 || echo "pmc group $g failed: $grp"
   f=$(find $O/g$g -name "*counter_collection.csv")
   [ -n "$f" ] && python3 $R/tools/pmc_summary_csv.py $f > $O/pmc_g$g.csv
+  if [ -n "$f" ] && { [ $g -le 2 ] || [ $g -eq 10 ]; }; then cp $f $O/raw_g$g.csv; fi
   rm -rf $O/g$g
 done
-cat $O/pmc_g*.csv | grep -i "spmv_row\|Kernel" > $O/summary.txt
+cat $O/pmc_g*.csv | grep -i "spmv_\|Kernel" > $O/summary.txt
+# per-launch HBM bytes of the SpMV kernels of this run (FETCH_SIZE correction from the bench passes' calibration)
+CF=${TRAFFIC_CAL:-$R/profiles/spmv_traffic.json}
+python3 $R/tools/pmc_traffic.py $O/raw_g1.csv $O/raw_g2.csv $O/raw_g10.csv $SIZE --correction-from $CF > $O/spmv_traffic.json
+rm -f $O/raw_g*.csv
 ls -la $O
