@@ -65,7 +65,8 @@ constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + p
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
 // LDS budget of a workgroup, two instantiations: LEAN (19 KiB: 8 workgroups = 32 waves per CU; rows of up to 8 entries --
 // the more tiles are resident, the more of them have their start-up loads behind them when their operands arrive) and
-// WIDE (38 KiB: 4 per CU; longer rows need room for a step's entries).
+// WIDE (38 KiB: 4 per CU; longer rows need room for a step's entries).  Round 3: rows of up to 16 entries take LEAN too (the plan cuts
+// its steps to the quad ring it is given): HPCG-256 3.13 -> 2.72 ms per sweep, same bits.
 template <int OWN, int EXT, int WINDOW, int RINGQ, int RINGSLOT, int QCHUNK, int SCHUNK>
 struct TiledCfg {
     static constexpr int kOwn = OWN;         // LDS ring of the tile's own results, by slot: an in-tile operand must have been
@@ -82,6 +83,7 @@ struct TiledCfg {
 using CfgLean = TiledCfg<512, 512, 128, 128, 256, 64, 128>;
 using CfgWide = TiledCfg<1024, 1024, 256, 256, 512, 128, 256>;
 constexpr int kMaxB = 32768;      // rows per tile at most
+constexpr int kLeanMaxLen = 16;   // rows of at most this many entries take the LEAN budget (option trsv_tile_lean)
 constexpr int kPollBlock = 128;   // external ordinals the poller has in flight (2 per lane); its watermark moves with the leading delivered ordinal
 constexpr unsigned kSpinLds = 1u << 26;  // polls of an LDS word before a wave gives up (several seconds: longer than the poller's budget below)
 constexpr unsigned kSpinMem = 1u << 20;  // polls of a memory word (about a second)
@@ -414,7 +416,7 @@ static bis_status trsv_tiled_build_host(bis_ctx *ctx, const bis_mat *T, bool bac
     if (st != BIS_OK) return st;
     int max_len = 0;
     for (int64_t r = 0; r < n; ++r) max_len = std::max<int>(max_len, (int)(rp[r + 1] - rp[r]));
-    const bool lean = max_len <= 8; // which LDS budget the sweep will run with (TiledCfg)
+    const bool lean = max_len <= (bis_opts().trsv_tile_lean >= 0 ? bis_opts().trsv_tile_lean : kLeanMaxLen); // which LDS budget the sweep will run with (TiledCfg)
     const int kOwn = lean ? CfgLean::kOwn : CfgWide::kOwn, kExt = lean ? CfgLean::kExt : CfgWide::kExt;
     const int kExtWindow = lean ? CfgLean::kExtWindow : CfgWide::kExtWindow, kRingQ = lean ? CfgLean::kRingQ : CfgWide::kRingQ;
     const int kZeroSlot = kOwn + kExt;
@@ -951,7 +953,7 @@ static bis_status trsv_tiled_build_device(bis_ctx *ctx, const bis_mat *T, bool b
     if (n == 0 || T->nnz == 0 || T->nnz > (int64_t)600000000 || T->view || n >= INT32_MAX) return BIS_OK;
     if (!(T->grid[0] > 0 && T->grid[0] * T->grid[1] * T->grid[2] * T->grid[3] == n)) return BIS_OK;
     const int max_len = T->max_row_nnz;
-    const bool lean = max_len <= 8;
+    const bool lean = max_len <= (bis_opts().trsv_tile_lean >= 0 ? bis_opts().trsv_tile_lean : kLeanMaxLen);
     PlanArgs a{};
     a.kOwn = lean ? CfgLean::kOwn : CfgWide::kOwn; a.kExt = lean ? CfgLean::kExt : CfgWide::kExt;
     a.kExtWindow = lean ? CfgLean::kExtWindow : CfgWide::kExtWindow; a.kRingQ = lean ? CfgLean::kRingQ : CfgWide::kRingQ;

@@ -208,9 +208,10 @@ def target_512(ctx, traffic_path, steps=10, warmup=3):
 
 
 def unstructured_spmv(ctx, launches=20):
-    """BASELINE config 5's SpMV: the CRS row-block kernel on the unstructured stand-in (fem:80,80,81, rows of 18-81
-    entries, more than 256 distinct values: no dictionary), HIP-event timed."""
-    A = ctx.gen_fem(80, 80, 81)
+    """BASELINE config 5's SpMV: the CRS row-block kernel on the unstructured stand-in (fem:80,80,80 -- the size the
+    PMC passes of tools/spmv_pmc.sh profile; rows of 18-81 entries, more than 256 distinct values: no dictionary),
+    HIP-event timed."""
+    A = ctx.gen_fem(80, 80, 80)
     N = A.n_rows
     import numpy as np
     x, y = ctx.upload(np.random.default_rng(12345).uniform(-1, 1, N)), ctx.alloc(N)
@@ -223,7 +224,7 @@ def unstructured_spmv(ctx, launches=20):
     ctx.sync()
     ctx.profile(False)
     n, ms = ctx.profile_read()
-    rec = {"workload": "fem:80,80,81 (stand-in for Flan_1565), y = A x", "rows": N, "nnz": A.nnz,
+    rec = {"workload": "fem:80,80,80 (stand-in for Flan_1565), y = A x", "rows": N, "nnz": A.nnz,
            "roofline": spmv_roofline(A, ms * 1e-3 / max(n, 1), n, os.path.join(ROOT, "profiles", "spmv_traffic_fem.json"), 80)}
     A.free(); x.free(); y.free()
     return rec

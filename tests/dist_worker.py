@@ -27,6 +27,31 @@ def gen(orc, kind, size, row0=0, row1=None):
     return orc.gen_anderson(size, shift=9.0, row0=row0, row1=row1)
 
 
+def closed_form_partition(kind, size, world, rank, row_starts):
+    """What a plane-aligned 1-D partition of the n^3 stencils must cost: every z-neighbour
+    rank contributes one n^2 plane of halo entries -- HPCG (open boundaries): one neighbour at the two ends, two in
+    between; Anderson (periodic): ranks 0 and P-1 are neighbours too, two neighbours everywhere once P > 2.  The
+    interior rows are the planes that touch no remote plane.  None when the partition is not plane-aligned."""
+    n2 = size * size
+    if any(int(r) % n2 for r in row_starts):
+        return None
+    planes = (int(row_starts[rank + 1]) - int(row_starts[rank])) // n2
+    if planes == 0 or world == 1:
+        return None
+    if kind == "hpcg":
+        nb = [q for q in (rank - 1, rank + 1) if 0 <= q < world]
+    else:
+        nb = sorted({(rank - 1) % world, (rank + 1) % world} - {rank})
+    # with two ranks of a periodic chain both faces go to the same neighbour: 2 n^2 entries from it
+    faces = 2 if kind != "hpcg" else len(nb)
+    halo = faces * n2
+    recv = {q: (halo // len(nb)) for q in nb}
+    lower = kind != "hpcg" or rank > 0          # is there a remote plane below / above this slab?
+    upper = kind != "hpcg" or rank < world - 1
+    interior = max(planes - int(lower) - int(upper), 0) * n2 if planes > 1 or not (lower or upper) else 0
+    return dict(halo=halo, neighbours=len(nb), recv=recv, interior_rows=interior, send=halo)
+
+
 def main():
     mode, kind, size = sys.argv[1], sys.argv[2], int(sys.argv[3])
     import torch
@@ -83,6 +108,12 @@ def main():
             assert np.all((c >= row0) & (c < row1))
         send_counts, send_cols = route_need_lists(halo, recv, rank, world, td)
         assert np.all((send_cols >= row0) & (send_cols < row1))
+        cf = closed_form_partition(kind, size, world, rank, row_starts)
+        if cf:  # closed forms of the plane-aligned partition: halo entries, neighbours, per-owner counts, interior rows, sends
+            assert len(halo) == cf["halo"] and int(np.count_nonzero(recv)) == cf["neighbours"] <= 2, (len(halo), recv, cf)
+            assert all(int(recv[q]) == c for q, c in cf["recv"].items()), (recv, cf)
+            assert b - a == cf["interior_rows"], (a, b, cf)
+            assert len(send_cols) == cf["send"] and int(np.count_nonzero(send_counts)) == cf["neighbours"]
         # renumber exactly as bis_dist_create does: owned -> c-row0, remote -> nl + index in halo
         col = A_loc.col.astype(np.int64)
         own = (col >= row0) & (col < row1)
@@ -158,6 +189,10 @@ def main():
         d_halo, d_recv = d.halo_info()
         assert np.array_equal(d_halo, h_halo) and np.array_equal(d_recv, h_recv)
         assert d.stats()["interior_rows"] == int(h_int[1] - h_int[0])
+        cf = closed_form_partition(kind, size, world, rank, row_starts)
+        if cf:
+            stt = d.stats()
+            assert stt["halo_entries"] == cf["halo"] and stt["interior_rows"] == cf["interior_rows"], (stt, cf)
         # Jacobi diagonal of the local rows from the device (bis_mat_diag) == the matrix' own
         dA2 = ctx.matrix(A_loc)
         dD, dDinv = ctx.mat_diag(dA2, row0)
@@ -191,6 +226,9 @@ def main():
         assert conv and dev <= 1e-10 and abs(iters - ref_cg["iters"]) <= 1, (conv, dev, iters)
         assert np.max(np.abs(xv.to_host() - ref_cg["x"][row0:row1])) <= 1e-9
         cg.free()
+        stt = d.stats()
+        if cf:
+            assert stt["send_entries"] == cf["send"] and stt["neighbours"] == cf["neighbours"] <= 2, (stt, cf)
         print(f"rank {rank}: distributed SpMV / dot / Jacobi-CG done", flush=True)
         if True:
             # `world` processes share ONE GPU here and all run persistent sweep grids at the same time: option

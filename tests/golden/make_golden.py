@@ -157,8 +157,48 @@ def histories(ref, orc, mats):
     return out
 
 
+# Mid-size inputs: full residual histories of the real reference at sizes where blocks, windows,
+# tiles and levels are many -- the HIP path is run on the same generator inputs (device generators, bit-identical to
+# the oracle's: tests/test_gpu_kernels.py) to convergence against them.  histories_mid.json, data only.
+MID_RUNS = [
+    ("hpcg48", "hpcg:48", lambda o: o.gen_hpcg(48), [("cg", "none", {}), ("cg", "j", {}), ("cg", "sgs", {})]),
+    ("hpcg32", "hpcg:32", lambda o: o.gen_hpcg(32), [("gs", "none", {}), ("sgs", "none", {}), ("j", "none", {})]),
+    ("anderson32_shift9", "anderson:32,shift=9", lambda o: o.gen_anderson(32, shift=9.0),
+     # (restart length 50: no restart before convergence -- a restart reads y[m] out of bounds in the reference,
+     # SURVEY.md section 5 defect 1, and the history behind it is not defined)
+     [("gm", "gs", dict(restart_len=50)), ("j", "none", {}), ("cg", "sgs", {})]),
+    ("fem_12x11x10", "fem:12,11,10", lambda o: o.gen_fem(12, 11, 10),
+     [("bi", "ilu0", dict(ilu_real=True)), ("cg", "j", {})]),
+]
+
+
+def histories_mid(ref, orc):
+    out = {}
+    for name, cli_arg, gen, runs in MID_RUNS:
+        A = gen(orc)
+        for solver, pc, kw in runs:
+            r = ref.solve(A, solver, pc, **kw)
+            o = orc.solve(A, solver, pc, **kw)
+            n = min(len(o["hist"]), len(r["hist"]))
+            d = np.abs(o["hist"][:n] - r["hist"][:n]) / r["hist"][0]
+            bad = np.nonzero(~(d <= 1e-9))[0]
+            key = f"{name}|{solver}|{pc}|" + ",".join(f"{k}={v}" for k, v in sorted(kw.items()))
+            out[key] = dict(cli=cli_arg, rows=A.n_rows, nnz=A.nnz, iters=r["iters"], converged=r["converged"],
+                            stopping=r["stopping"], final_true_residual=r["final_true_residual"],
+                            hist=[float(v) for v in r["hist"]], stable_len=int(bad[0]) if len(bad) else int(n),
+                            oracle_max_dev_over_r0=float(np.max(d)))
+            print(key, r["iters"], r["converged"], f"oracle dev {np.max(d):.2e}", flush=True)
+    with open(os.path.join(HERE, "histories_mid.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    return out
+
+
 def main():
     ref, orc = Ref(), Oracle()
+    if "--mid-only" in sys.argv:  # leaves the small fixtures as they are
+        h = histories_mid(ref, orc)
+        print(f"wrote {len(h)} mid-size histories")
+        return
     mats = {}
     for name in ("FDM-2d-16", "matrix_band_klein"):
         A = ref.read_mtx(os.path.join(HERE, name + ".mtx"))
@@ -174,6 +214,7 @@ def main():
     n_clean = sum(1 for k, v in h.items() if v.get("restart_clean", True))
     print(f"wrote {len(h)} histories ({n_clean} complete) and "
           f"{len(mats) + 1} kernel fixture files")
+    histories_mid(ref, orc)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,25 @@ def load_histories():
         return json.load(f)
 
 
+def load_histories_mid():
+    """Mid-size reference histories (tests/golden/make_golden.py --mid-only): inputs are generator strings."""
+    with open(os.path.join(GOLDEN, "histories_mid.json")) as f:
+        return json.load(f)
+
+
+def gen_from_cli_arg(orc, arg):
+    """The oracle's matrix for a host-CLI generator string (hpcg:N | anderson:L,shift=S | fem:X,Y,Z)."""
+    kind, rest = arg.split(":")
+    parts = rest.split(",")
+    nums = [int(p) for p in parts if "=" not in p]
+    kw = {k: float(v) for k, v in (p.split("=") for p in parts if "=" in p)}
+    if kind == "hpcg":
+        return orc.gen_hpcg(*nums)
+    if kind == "anderson":
+        return orc.gen_anderson(nums[0], shift=kw.get("shift", 0.0))
+    return orc.gen_fem(*nums)
+
+
 def parse_hist_key(key):
     name, solver, pc, kws = key.split("|")
     kw = {}

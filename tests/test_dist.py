@@ -30,9 +30,14 @@ def launch(world, mode, kind, size, timeout=600):
     assert out.stdout.count(" OK") == world, out.stdout[-2000:]
 
 
-@pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 8), (3, "anderson", 6), (2, "anderson", 5)])
+@pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 8), (3, "anderson", 6), (2, "anderson", 5),
+                                             # the 8-way partition the metric is quoted on: plane-aligned slabs of HPCG
+                                             # (2 planes per rank), periodic Anderson with one plane per rank (ranks 0 and
+                                             # 7 exchange); closed-form halo / neighbour / interior counts, P = 8 history
+                                             # equal to the P = 1 history to 1e-10 r0 (tests/dist_worker.py)
+                                             (8, "hpcg", 16), (8, "anderson", 8), (4, "anderson", 8)])
 def test_partitioned_cg_gloo_cpu(world, kind, size):
-    launch(world, "cpu", kind, size)
+    launch(world, "cpu", kind, size, timeout=900)
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -43,7 +48,10 @@ def test_rccl_negotiation_is_collective(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 12), (3, "anderson", 7), (1, "hpcg", 8)])
+@pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 12), (3, "anderson", 7), (1, "hpcg", 8),
+                                             # more ranks on the one GPU (the box allows six GPU processes): plane-aligned
+                                             # HPCG slabs and the periodic Anderson chain with its wrap-around neighbour
+                                             (4, "hpcg", 8), (5, "anderson", 5)])
 def test_partitioned_cg_hip(world, kind, size):
     launch(world, "gpu", kind, size)
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import (GOLDEN, GOLDEN_MATS, check_history, crs_of, load_golden,
-                     load_histories, parse_hist_key, relerr)
+                     load_histories, load_histories_mid, gen_from_cli_arg, parse_hist_key, relerr)
 from oracle.pyoracle import CRS
 
 KTOL = 1e-13  # kernel-level relative tolerance (SURVEY.md 8d parity gate)
@@ -120,6 +120,19 @@ def test_residual_history_vs_golden(oracle, key):
     name, solver, pc, kw = parse_hist_key(key)
     A = crs_of(load_golden(name), "A")
     r = oracle.solve(A, solver, pc, **kw)
+    check_history(r, e, solver)
+
+
+_HM = load_histories_mid()
+
+
+@pytest.mark.parametrize("key", sorted(k for k in _HM if _HM[k]["rows"] <= 40000))
+def test_mid_size_residual_history_vs_golden(oracle, key):
+    """The same gate on the mid-size inputs (generator strings; HPCG-32, Anderson-32, the FEM stand-in) whose
+    reference histories tests/golden/histories_mid.json holds; the largest (HPCG-48) is left to the GPU suite."""
+    e = _HM[key]
+    name, solver, pc, kw = parse_hist_key(key)
+    r = oracle.solve(gen_from_cli_arg(oracle, e["cli"]), solver, pc, **kw)
     check_history(r, e, solver)
 
 

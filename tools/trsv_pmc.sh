@@ -14,6 +14,8 @@ GROUPS_=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
  "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU"
  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum GRBM_GUI_ACTIVE"
+ "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"
+ "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY"
 )
 run_cfg() { # name, args...
   name=$1; shift
@@ -30,5 +32,10 @@ run_cfg() { # name, args...
   rm -rf $O/${name}_trace
 }
 run_cfg anderson256_gm_gs anderson:256,shift=9 -gm -p gs &&
-run_cfg fem_bi_ilu0 fem:80,80,81 -bi -p ilu0
+run_cfg fem_bi_ilu0 fem:80,80,81 -bi -p ilu0 &&
+run_cfg hpcg256_cg_sgs hpcg:256 -cg -p sgs
+# one file per configuration: kernel statistics and the counters of the sweep kernels
+for n in anderson256_gm_gs fem_bi_ilu0 hpcg256_cg_sgs; do
+  cat $O/${n}_pmc_g*.csv | grep -i "Kernel\|trsv\|sptrsv" > $O/${n}_pmc.csv
+done
 ls -la $O
