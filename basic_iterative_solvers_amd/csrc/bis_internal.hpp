@@ -87,6 +87,7 @@ struct bis_options {
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
     int spmv_sellwin = -1; // dictionary SpMV with the block's x window in LDS and sliced-ELL codes (bis_spmv_sell.hip): 0 off (-1: on where the matrix qualifies)
     int spmv_sellwin_rows = -1; // rows per lane of the sliced-ELL form: 1 or 2 (blocks of 256 or 512 rows; -1: default 2)
+    int spmv_sellwin_pairs = -1; // 0: never the one-byte (column - row, value) pair codes
     int spmv_sellwin_joint = -1; // 0: never the 16-bit joint (slot, value) codes
     int device_share = -1;  // k > 1: this device is shared by k processes that all run persistent grids (several ranks on one GPU in a test
                             // or rehearsal): kernels that need their whole grid resident keep to 1/k of the device

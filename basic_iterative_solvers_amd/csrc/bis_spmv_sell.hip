@@ -14,6 +14,10 @@
 //     Where the table (dictionary + padding value [+ the per-row-diagonal marker]) has at most 8 entries -- every
 //     constant-coefficient stencil -- a non-zero is ONE 16-bit code, window slot : 13 | table index : 3, 8 bytes per
 //     lane and chunk: 2 streamed bytes per non-zero.
+//     Where the matrix has at most 253 distinct (column - row, value) pairs -- a stencil on a structured grid has as
+//     many as it has points -- and, inside every block, the columns of each pair run through the window in step with
+//     the rows (window slot = base of the pair in this block + row: true when they lie in one run), a non-zero is ONE
+//     BYTE: the index of its pair; the block brings its bases (2 bytes per pair).  1 streamed byte per non-zero.
 //   * a block is 256 R rows (R = 1, 2, 4 rows per lane, one 64-row slice after the other): the larger R, the fewer
 //     times an x entry is copied into some block's window (HPCG: 9 x at R = 1, 6 x at R = 2), at a larger window.
 //     A slice has as many chunks as its longest row needs; shorter rows are padded with an entry that is neutral in
@@ -26,6 +30,9 @@
 // keeps the gather kernels.
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -36,11 +43,17 @@ struct bis_sellwin {
     int64_t n_slices = 0, total_chunks = 0;
     int32_t *hdr = nullptr;          // [n_blocks * 64]: words 0..31 first granule of run k, words 32..63 (rank of the run's first granule in the window) | (granules << 16)
     int64_t *slice_chunk0 = nullptr; // [n_slices + 1]
-    uint32_t *codes = nullptr;       // [(total_chunks + 1) * 64 * (fmt == 2 ? 2 : 3)]
+    int32_t *own_rank = nullptr;     // [n_blocks] rank (in the window) of the granule of the block's first row's OWN column (row + view_row0) when the
+                                     // own columns of all the block's rows lie in the window side by side, else -1: the fused dot then takes w from LDS
+    uint32_t *codes = nullptr;       // [(total_chunks + 1) * 64 * words], words = 3, 3, 2, 1 for fmt 0..3
     double *dict = nullptr;          // [256] the matrix' dictionary plus the padding value 1.0
     int max_gran = 0;                // largest window of a block, in granules
     int fmt = 0;                     // 0: 12-byte chunks, value byte = table index; 1: value byte = 8 * index (<= 32 entries);
-                                     // 2: 8-byte chunks, 16-bit codes slot : 13 | index : 3 (<= 8 entries)
+                                     // 2: 8-byte chunks, 16-bit codes slot : 13 | index : 3 (<= 8 entries);
+                                     // 3: 4-byte chunks, one byte per non-zero = index of its (column - row, value) pair
+    int n_pairs = 0, pair_stride = 0, diag_pair = -1; // fmt 3: pairs of the matrix, int16 words per block in blk_base, the per-row-diagonal pair
+    int16_t *blk_base = nullptr;     // fmt 3: [n_blocks * pair_stride] window slot of pair e's column for the block's first row
+    unsigned long long *pair_key = nullptr; // fmt 3: [256] the pairs, ascending ((uint32)(column - row) << 8 | value code)
     int R = 1;                       // rows per lane: a block is 256 R rows
     bool diag = false;               // one value code stands for the row's own diagonal value (vdiag)
     int pad_idx = 0, diag_idx = 0;
@@ -54,8 +67,9 @@ constexpr int kSwRunGran = 64; // granules per run at most
 constexpr int kSwHash = 4096;
 constexpr int kSwMaxGran = 940; // window <= (2 + 8 * 940) * 8 = 60176 bytes (list[1024] in the plan kernel, 13-bit slots in the joint codes)
 constexpr int kSwDefaultR = 2;
+constexpr int kSwMaxPairs = 253; // fmt 3: pairs of a matrix at most (the padding takes the next index)
 // ... and with the tables in front of it the workgroup stays within 64 KiB of LDS
-inline int sw_gran_cap(int R) { return std::min(kSwMaxGran, (65536 - (2048 + 2048 * R) - 16) / 64); }
+inline int sw_gran_cap(int R) { return std::min(kSwMaxGran, (65536 - (4096 + 4096 * R) - 16) / 64); } // (the largest table area: fmt 3 with per-row diagonals)
 
 __device__ __forceinline__ int sw_wave_max(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
@@ -66,8 +80,8 @@ __device__ __forceinline__ int sw_wave_max(int v) {
 // into runs of consecutive granules; chunks per slice.  status[0] = 1: not representable; status[1] = max granules.
 template <typename RP>
 __global__ __launch_bounds__(256) void sw_plan_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
-                                                      int64_t n_rows, int R, int max_gran, int32_t *__restrict__ hdr,
-                                                      int32_t *__restrict__ slice_chunks, int *status) {
+                                                      int64_t n_rows, int R, int max_gran, int64_t row0, int32_t *__restrict__ hdr,
+                                                      int32_t *__restrict__ slice_chunks, int32_t *__restrict__ own_rank, int *status) {
     __shared__ int table[kSwHash];
     __shared__ int list[1024];
     __shared__ int cnt, n_runs, failed;
@@ -133,6 +147,17 @@ __global__ __launch_bounds__(256) void sw_plan_kernel(const RP *__restrict__ row
             }
             __syncthreads();
         }
+    if (tid == 0) { // are the granules of the block's own columns (row + row0) all in the window, side by side?
+        const int64_t c_first = r0 + row0, c_last = c_first + rows - 1;
+        int own = -1;
+        if ((c_first & 7) == 0) {
+            const int g_first = (int)(c_first >> 3), g_last = (int)(c_last >> 3);
+            int lo = 0, hi = n - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (list[mid] < g_first) lo = mid + 1; else hi = mid; }
+            if (n > 0 && list[lo] == g_first && lo + (g_last - g_first) < n && list[lo + (g_last - g_first)] == g_last) own = lo;
+        }
+        own_rank[b] = own;
+    }
     for (int i = tid; i < n; i += 256)
         if (i == 0 || list[i] != list[i - 1] + 1) {
             const int idx = atomicAdd(&n_runs, 1);
@@ -250,11 +275,124 @@ __global__ __launch_bounds__(256) void sw_fill_kernel(const RP *__restrict__ row
     }
 }
 
+// fmt 3, step 1: the distinct (column - row, value code) pairs of the matrix, one list per wave (a workgroup is one
+// wave): lists[w * 257] = count (more than 254: *overflow is raised and every wave stops), then the keys.
+template <typename RP>
+__global__ __launch_bounds__(64) void sw_pairs_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                      const uint8_t *__restrict__ vcode, int64_t vd_base, int64_t n_rows, int64_t row0,
+                                                      unsigned long long *__restrict__ lists, int *overflow) {
+    __shared__ unsigned long long list[256];
+    const int lane = threadIdx.x;
+    int n = 0;
+    for (int64_t rb = (int64_t)blockIdx.x * 64; rb < n_rows && n <= kSwMaxPairs; rb += (int64_t)gridDim.x * 64) {
+        if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { n = kSwMaxPairs + 1; break; }
+        const int64_t r = rb + lane;
+        int64_t k = 0, k1 = 0;
+        if (r < n_rows) { k = (int64_t)row_ptr[r]; k1 = (int64_t)row_ptr[r + 1]; }
+        while (__ballot(k < k1) && n <= kSwMaxPairs) {
+            bool found = true;
+            unsigned long long v = 0;
+            if (k < k1) {
+                v = ((unsigned long long)(unsigned)(col[k] - (int32_t)(r + row0)) << 8) | vcode[k - vd_base];
+                found = false;
+                ++k;
+            }
+            for (int j = 0; j < n && __ballot(!found); ++j) found |= list[j] == v;
+            while (const unsigned long long open = __ballot(!found)) {
+                const int leader = (int)__builtin_ctzll(open);
+                const unsigned long long lv = __shfl(v, leader);
+                if (n == kSwMaxPairs) { n = kSwMaxPairs + 1; break; }
+                if (lane == 0) list[n] = lv;
+                ++n;
+                found |= v == lv;
+            }
+            __syncthreads();
+        }
+    }
+    if (n > kSwMaxPairs && lane == 0) atomicExch(overflow, 1);
+    if (lane == 0) lists[(size_t)blockIdx.x * 257] = (unsigned long long)n;
+    for (int j = lane; j < n && j < 256; j += 64) lists[(size_t)blockIdx.x * 257 + 1 + j] = list[j];
+}
+
+// fmt 3, step 2: one byte per non-zero = index of its pair; the block's bases.  A pair whose columns do not run through
+// the window in step with the rows (slot != base + row for some row of the block) raises status[2]: another format then.
+template <typename RP>
+__global__ __launch_bounds__(256) void sw_fill_pairs_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                            const uint8_t *__restrict__ vcode, int64_t vd_base, int64_t n_rows, int64_t row0,
+                                                            int R, const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
+                                                            uint32_t *__restrict__ codes, const unsigned long long *__restrict__ pair_key,
+                                                            int n_pairs, int pair_stride, int16_t *__restrict__ blk_base, int *status) {
+    __shared__ int g0s[kSwRuns], rk[kSwRuns];
+    __shared__ int nr_s;
+    __shared__ unsigned long long keys[256];
+    __shared__ int base[256];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    keys[tid] = pair_key[tid];
+    base[tid] = INT32_MIN;
+    if (tid < kSwRuns) {
+        g0s[tid] = hdr[(size_t)b * 64 + tid];
+        const int w2 = hdr[(size_t)b * 64 + 32 + tid];
+        rk[tid] = w2 & 0xffff;
+        const unsigned long long m = __ballot((w2 >> 16) != 0);
+        if (tid == 0) nr_s = __popcll(m);
+    }
+    __syncthreads();
+    const int nr = nr_s;
+    bool bad = false;
+    for (int rr = 0; rr < R; ++rr) {
+        const int64_t slice = ((int64_t)b * 4 + wv) * R + rr;
+        const int64_t r = slice * 64 + lane;
+        const int r_in_block = (wv * R + rr) * 64 + lane;
+        int64_t rs = 0;
+        int len = 0;
+        if (r < n_rows) {
+            rs = (int64_t)row_ptr[r];
+            len = (int)((int64_t)row_ptr[r + 1] - rs);
+        }
+        const int64_t c0 = slice_chunk0[slice];
+        const int nch = (int)(slice_chunk0[slice + 1] - c0);
+        for (int c = 0; c < nch; ++c) {
+            unsigned word = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * c + q;
+                unsigned e = (unsigned)n_pairs; // padding
+                if (j < len) {
+                    const int ci = col[rs + j];
+                    const unsigned long long key = ((unsigned long long)(unsigned)(ci - (int32_t)(r + row0)) << 8) | vcode[rs + j - vd_base];
+                    int lo = 0, hi = n_pairs - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                    }
+                    e = (unsigned)lo;
+                    const int g = ci >> 3;
+                    int rl = 0, rh = nr - 1;
+                    while (rl < rh) {
+                        const int mid = (rl + rh + 1) >> 1;
+                        if (g0s[mid] <= g) rl = mid; else rh = mid - 1;
+                    }
+                    const int delta = 2 + (rk[rl] + (g - g0s[rl])) * 8 + (ci & 7) - r_in_block;
+                    const int old = atomicCAS(&base[lo], INT32_MIN, delta);
+                    bad |= old != INT32_MIN && old != delta;
+                }
+                word |= e << (8 * q);
+            }
+            codes[(size_t)(c0 + c) * 64 + lane] = word;
+        }
+    }
+    if (bad) atomicExch(&status[2], 1);
+    __syncthreads();
+    if (tid < pair_stride) blk_base[(size_t)b * pair_stride + tid] = base[tid] == INT32_MIN ? (int16_t)0 : (int16_t)base[tid];
+}
+
 template <int FMT> struct sw_chunk { uint32_t a, b, c; };
 template <> struct sw_chunk<2> { uint32_t a, b; };
+template <> struct sw_chunk<3> { uint32_t a; };
 
 template <bool DIAG, int FMT, int R>
 struct SwLayout {
+    // (fmt 3 sizes its table by the matrix' pairs: its offsets are run-time values, sw_layout3)
     static constexpr int kDictBytes = FMT == 2 ? 64 : (FMT == 1 ? 256 : 2048);
     static constexpr int kDiagOff = kDictBytes;
     static constexpr int kWinOff = kDictBytes + (DIAG ? 2048 * R : 0);
@@ -262,6 +400,36 @@ struct SwLayout {
 };
 
 // four non-zeros of every row of the wave: acc += table[value code] * window[column code], in entry order
+// fmt 3.  LDS: table entries of 16 bytes {value; LDS address of the pair's column for the block's first row; mask}, the
+// per-row diagonal values (DIAG), one slot of -0.0, the window.  x address = entry address + (8 * row in block & mask): the
+// padding entry points at the -0.0 slot with mask 0, whatever the lane.
+struct SwLayout3 { int tab_bytes, diag_off, pad_off, win_off; };
+__host__ __device__ inline SwLayout3 sw_layout3(int n_pairs, bool diag, int R) {
+    SwLayout3 l;
+    l.tab_bytes = (16 * (n_pairs + 1) + 255) & ~255;
+    l.diag_off = l.tab_bytes;
+    l.pad_off = l.diag_off + (diag ? 2048 * R : 0);
+    l.win_off = l.pad_off; // the window's own first slot is the -0.0 one
+    return l;
+}
+// diag_code = 16 * (index of the per-row-diagonal pair), row_off = 8 * (row in block)
+template <bool DIAG, int R>
+__device__ __forceinline__ void sw_chunk_fma3(const unsigned char *lds, const sw_chunk<3> &cd, unsigned diag_rel, unsigned diag_code,
+                                              unsigned row_off, double &acc) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned ea = ((cd.a >> (8 * q)) & 0xffu) << 4;
+        const uint2 xm = *reinterpret_cast<const uint2 *>(lds + ea + 8);
+        unsigned va = ea;
+        if (DIAG) va = ea == diag_code ? diag_rel : ea;
+        const double v = *reinterpret_cast<const double *>(lds + va);
+        const double xv = *reinterpret_cast<const double *>(lds + (xm.x + (row_off & xm.y)));
+        const double pr = v * xv;
+        acc = acc + pr;
+    }
+}
+
 template <bool DIAG, int FMT, int R>
 __device__ __forceinline__ void sw_chunk_fma(const unsigned char *lds, const sw_chunk<FMT> &cd, unsigned diag_rel, double &acc) {
 #pragma clang fp contract(off)
@@ -288,9 +456,13 @@ __device__ __forceinline__ void sw_chunk_fma(const unsigned char *lds, const sw_
 }
 
 template <int Q, bool DIAG, int FMT, int R>
-__device__ __forceinline__ void sw_consume(const unsigned char *lds, const sw_chunk<FMT> (&cd)[8], unsigned diag_rel, double &acc) {
+__device__ __forceinline__ void sw_consume(const unsigned char *lds, const sw_chunk<FMT> (&cd)[8], unsigned diag_rel, unsigned diag_code,
+                                           unsigned row_off, double &acc) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) sw_chunk_fma<DIAG, FMT, R>(lds, cd[q], diag_rel, acc);
+    for (int q = 0; q < Q; ++q) {
+        if constexpr (FMT == 3) sw_chunk_fma3<DIAG, R>(lds, cd[q], diag_rel, diag_code, row_off, acc);
+        else sw_chunk_fma<DIAG, FMT, R>(lds, cd[q], diag_rel, acc);
+    }
 }
 
 // MODE 0: y = A x.  MODE 1: also partials[slice] = sum over the slice's rows of y[r] w[r] (CG's (Ap, p)).
@@ -298,7 +470,8 @@ template <int MODE, bool DIAG, int FMT, int R>
 __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
     double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
-    const uint32_t *__restrict__ codes, const double *__restrict__ dict_g, const double *__restrict__ vdiag, int x_al16) {
+    const uint32_t *__restrict__ codes, const double *__restrict__ dict_g, const double *__restrict__ vdiag, int x_al16,
+    const int16_t *__restrict__ blk_base, int pair_stride, int n_pairs, int diag_pair, const int32_t *__restrict__ own_rank, long long *dbg) {
     using L = SwLayout<DIAG, FMT, R>;
     using Chunk = sw_chunk<FMT>;
     if (stop && stop[1]) return;
@@ -308,6 +481,7 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     if (b >= n_blocks) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long t_start = dbg ? (long long)__builtin_readcyclecounter() : 0; // diagnostic stamps (BIS_SELLWIN_DEBUG): shader cycles
     const int hw = hdr[(size_t)b * 64 + lane];
     const int64_t slice0 = ((int64_t)b * 4 + wv) * R; // this wave's R consecutive slices
     int64_t c0[R];
@@ -324,21 +498,41 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
         for (int q = 0; q < 8; ++q) cd[r][q] = cp[(size_t)min(q, last) * 64];
         const int64_t row = (slice0 + r) * 64 + lane;
         wr[r] = 0.0;
-        if (MODE == 1 && row < n_rows) wr[r] = w[row];
+        if (MODE == 1 && !own_rank && row < n_rows) wr[r] = w[row];
         if (DIAG) dval[r] = row < n_rows ? vdiag[row] : 0.0;
     }
+    // own_rank != nullptr: w is x at the rows' own columns (CG: w = x = p) -- where the block's window holds them side by side
+    // the dot's operand comes from LDS behind the barrier instead of a second global read of p
+    int own = -1;
+    if (MODE == 1 && own_rank) {
+        own = own_rank[b];
+        if (own < 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int64_t row = (slice0 + r) * 64 + lane; if (row < n_rows) wr[r] = w[row]; }
+        }
+    }
     // tables
-    if (tid < L::kDictBytes / 8) reinterpret_cast<double *>(lds)[tid] = dict_g[tid];
+    const SwLayout3 l3 = sw_layout3(n_pairs, DIAG, R);
+    const int win_off = FMT == 3 ? l3.win_off : L::kWinOff, diag_off = FMT == 3 ? l3.diag_off : L::kDiagOff;
+    if constexpr (FMT == 3) { // entry e: {value of pair e; LDS address of its column for the block's first row; mask}; the padding: 1.0 at the -0.0 slot
+        if (tid <= n_pairs) {
+            int xo = l3.pad_off, mask = 0;
+            if (tid < n_pairs) { xo = l3.win_off + 8 * (int)blk_base[(size_t)b * pair_stride + tid]; mask = -1; }
+            *reinterpret_cast<double *>(lds + 16 * tid) = dict_g[tid];
+            *reinterpret_cast<int2 *>(lds + 16 * tid + 8) = make_int2(xo, mask);
+        }
+    } else if (tid < L::kDictBytes / 8) reinterpret_cast<double *>(lds)[tid] = dict_g[tid];
     if (DIAG) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) reinterpret_cast<double *>(lds + L::kDiagOff)[(wv * R + r) * 64 + lane] = dval[r];
+        for (int r = 0; r < R; ++r) reinterpret_cast<double *>(lds + diag_off)[(wv * R + r) * 64 + lane] = dval[r];
     }
-    if (tid == 0) *reinterpret_cast<double *>(lds + L::kWinOff) = -0.0;
+    if (tid == 0) *reinterpret_cast<double *>(lds + win_off) = -0.0;
     // window: the runs of 8-column granules; a run has at most 256 pieces of 16 bytes, a wave takes 64 of them and
     // the hardware writes them to LDS behind the wave-uniform base (no register staging, nothing waited for here)
     {
         const int n_runs = __popcll(__ballot(lane >= 32 && (hw >> 16) != 0));
-        unsigned char *win = lds + L::kWinOff + 16;
+        if (dbg && tid == 0) dbg[(size_t)b * 4 + 1] = (long long)__builtin_readcyclecounter() - t_start; // header arrived
+        unsigned char *win = lds + win_off + 16;
         for (int k = 0; k < n_runs; ++k) {
             const int g0 = __builtin_amdgcn_readlane(hw, k);
             const int w2 = __builtin_amdgcn_readlane(hw, 32 + k);
@@ -361,9 +555,11 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
         }
     }
     __syncthreads();
+    if (dbg && tid == 0) dbg[(size_t)b * 4 + 2] = (long long)__builtin_readcyclecounter() - t_start; // window and codes arrived, barrier passed
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const unsigned diag_rel = (unsigned)(L::kDiagOff + ((wv * R + r) * 64 + lane) * 8);
+        const unsigned diag_rel = (unsigned)(diag_off + ((wv * R + r) * 64 + lane) * 8);
+        const unsigned row_off = (unsigned)(((wv * R + r) * 64 + lane) * 8), diag_code = (unsigned)diag_pair << 4;
         const Chunk *cp = reinterpret_cast<const Chunk *>(codes) + (size_t)c0[r] * 64 + lane;
         double acc = 0.0;
         for (int cb = 0; cb < nch[r]; cb += 8) {
@@ -373,23 +569,25 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
                 for (int q = 0; q < 8; ++q) cd[r][q] = cp[(size_t)(cb + min(q, rem - 1)) * 64];
             }
             switch (rem) {
-            case 1: sw_consume<1, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
-            case 2: sw_consume<2, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
-            case 3: sw_consume<3, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
-            case 4: sw_consume<4, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
-            case 5: sw_consume<5, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
-            case 6: sw_consume<6, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
-            case 7: sw_consume<7, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
-            default: sw_consume<8, DIAG, FMT, R>(lds, cd[r], diag_rel, acc); break;
+            case 1: sw_consume<1, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc); break;
+            case 2: sw_consume<2, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc); break;
+            case 3: sw_consume<3, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc); break;
+            case 4: sw_consume<4, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc); break;
+            case 5: sw_consume<5, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc); break;
+            case 6: sw_consume<6, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc); break;
+            case 7: sw_consume<7, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc); break;
+            default: sw_consume<8, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc); break;
             }
         }
         const int64_t row = (slice0 + r) * 64 + lane;
         if (row < n_rows) y[row] = acc;
         if (MODE == 1) {
+            if (own >= 0) wr[r] = *reinterpret_cast<const double *>(lds + win_off + 16 + ((size_t)own * 8 + (wv * R + r) * 64 + lane) * 8);
             const double t = wave_sum(row < n_rows ? acc * wr[r] : 0.0);
             if (lane == 0) partials[slice0 + r] = t;
         }
     }
+    if (dbg && tid == 0) { dbg[(size_t)b * 4 + 3] = (long long)__builtin_readcyclecounter() - t_start; dbg[(size_t)b * 4] = t_start; }
 }
 
 bool sw_enabled() { return bis_opts().spmv_sellwin != 0; }
@@ -398,7 +596,7 @@ bool sw_enabled() { return bis_opts().spmv_sellwin != 0; }
 
 void bis_spmv_sellwin_drop(bis_mat *A) {
     if (A->sw) {
-        hipFree(A->sw->hdr); hipFree(A->sw->slice_chunk0); hipFree(A->sw->codes); hipFree(A->sw->dict);
+        hipFree(A->sw->hdr); hipFree(A->sw->slice_chunk0); hipFree(A->sw->own_rank); hipFree(A->sw->codes); hipFree(A->sw->dict); hipFree(A->sw->blk_base); hipFree(A->sw->pair_key);
         delete A->sw;
         A->sw = nullptr;
     }
@@ -418,6 +616,95 @@ void bis_spmv_sellwin_drop(bis_mat *A) {
             return BIS_ERR_HIP;                                                \
         }                                                                      \
     } while (0)
+
+// fmt 3 on top of a finished plan (A->sw: runs, slices, chunk offsets).  Leaves A->sw_state == 1 on success; on "does not
+// apply" everything it allocated is freed and the caller goes on with another format; an out-of-memory drops the form.
+static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, int pad_idx) {
+    bis_sellwin *sw = A->sw;
+    int32_t *slice_chunks = nullptr; // (SW_CHECK's clean-up names)
+    void *tmp = nullptr;
+    const int n_waves = (int)std::min<int64_t>((A->n_rows + 63) / 64, (int64_t)ctx->n_cus * 8);
+    unsigned long long *lists = nullptr;
+    int *status = (int *)ctx->counters + 52;
+    SW_CHECK(hipMalloc(&lists, sizeof(unsigned long long) * 257 * (size_t)n_waves));
+    tmp = lists;
+    SW_CHECK(hipMemsetAsync(status + 2, 0, 2 * sizeof(int), ctx->stream));
+    if (A->rp64) hipLaunchKernelGGL(sw_pairs_kernel<int64_t>, dim3(n_waves), dim3(64), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, A->view_row0, lists, status + 3);
+    else hipLaunchKernelGGL(sw_pairs_kernel<int32_t>, dim3(n_waves), dim3(64), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, A->view_row0, lists, status + 3);
+    SW_CHECK(hipGetLastError());
+    std::vector<unsigned long long> h((size_t)257 * n_waves);
+    int over = 0;
+    SW_CHECK(hipMemcpyAsync(&over, status + 3, sizeof over, hipMemcpyDeviceToHost, ctx->stream));
+    SW_CHECK(hipMemcpyAsync(h.data(), lists, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SW_CHECK(hipStreamSynchronize(ctx->stream));
+    hipFree(lists); tmp = nullptr;
+    if (over) return BIS_OK;
+    std::vector<unsigned long long> all;
+    for (int w = 0; w < n_waves; ++w) {
+        const size_t n = (size_t)h[(size_t)w * 257];
+        if (n > (size_t)kSwMaxPairs) return BIS_OK;
+        all.insert(all.end(), h.begin() + (size_t)w * 257 + 1, h.begin() + (size_t)w * 257 + 1 + n);
+    }
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    if (all.empty() || all.size() > (size_t)kSwMaxPairs) return BIS_OK;
+    const int n_pairs = (int)all.size();
+    unsigned long long keys[256];
+    double vals[256];
+    int diag_pair = -1;
+    for (int e = 0; e < 256; ++e) { keys[e] = ~0ull; vals[e] = 0.0; }
+    for (int e = 0; e < n_pairs; ++e) {
+        keys[e] = all[e];
+        const unsigned vc = (unsigned)(all[e] & 0xffu);
+        if (A->vd_diag && vc == 255u) {
+            if (diag_pair >= 0) return BIS_OK; // diagonal entries at several offsets (a row view's numbering): another format
+            diag_pair = e;
+        } else vals[e] = table[vc];
+    }
+    vals[n_pairs] = table[pad_idx]; // the padding entry: 1.0
+    const int stride = (n_pairs + 63) / 64 * 64;
+    const int64_t total = sw->total_chunks;
+    const int nb = sw->n_blocks;
+    int16_t *blk_base = nullptr;
+    unsigned long long *pair_key = nullptr;
+    uint32_t *codes = nullptr;
+    double *dict3 = nullptr;
+    hipError_t e = hipMalloc(&blk_base, sizeof(int16_t) * (size_t)stride * (size_t)nb);
+    if (e == hipSuccess) e = hipMalloc(&pair_key, sizeof keys);
+    if (e == hipSuccess) e = hipMalloc(&codes, sizeof(uint32_t) * 64 * (size_t)(total + 1));
+    if (e == hipSuccess) e = hipMalloc(&dict3, sizeof vals);
+    if (e == hipSuccess) e = hipMemcpyAsync(pair_key, keys, sizeof keys, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dict3, vals, sizeof vals, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(codes + (size_t)total * 64, 0, sizeof(uint32_t) * 64, ctx->stream);
+    if (e == hipSuccess) {
+#define SW_FILLP(RP) hipLaunchKernelGGL((sw_fill_pairs_kernel<RP>), dim3(nb), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, A->view_row0, sw->R, sw->hdr, sw->slice_chunk0, codes, pair_key, n_pairs, stride, blk_base, status)
+        if (A->rp64) SW_FILLP(int64_t); else SW_FILLP(int32_t);
+#undef SW_FILLP
+        e = hipGetLastError();
+    }
+    int bad = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, status + 2, sizeof bad, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // keys[], vals[], bad
+    if (e != hipSuccess || bad) {
+        hipFree(blk_base); hipFree(pair_key); hipFree(codes); hipFree(dict3);
+        if (e == hipSuccess || e == hipErrorOutOfMemory) { (void)hipGetLastError(); return BIS_OK; } // another format
+        ctx->err = std::string("bis_spmv sellwin pairs: ") + hipGetErrorString(e);
+        bis_spmv_sellwin_drop(A);
+        A->sw_state = -1;
+        return BIS_ERR_HIP;
+    }
+    hipFree(sw->dict);
+    sw->dict = dict3;
+    sw->codes = codes;
+    sw->blk_base = blk_base;
+    sw->pair_key = pair_key;
+    sw->fmt = 3;
+    sw->n_pairs = n_pairs;
+    sw->pair_stride = stride;
+    sw->diag_pair = diag_pair;
+    A->sw_state = 1;
+    return BIS_OK;
+}
 
 // Build the form for a matrix that has a value dictionary (A->vd_state == 1); A->sw_state tells the outcome.
 bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
@@ -459,14 +746,16 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     void *tmp = nullptr;
     int *status = (int *)ctx->counters + 52;
     SW_CHECK(hipMalloc(&sw->hdr, sizeof(int32_t) * 64 * (size_t)nb));
+    SW_CHECK(hipMalloc(&sw->own_rank, sizeof(int32_t) * (size_t)nb));
+    SW_CHECK(hipMemsetAsync(sw->own_rank, 0xFF, sizeof(int32_t) * (size_t)nb, ctx->stream)); // (blocks the plan leaves early: -1)
     SW_CHECK(hipMalloc(&slice_chunks, sizeof(int32_t) * (size_t)(sw->n_slices + 1)));
     SW_CHECK(hipMalloc(&sw->slice_chunk0, sizeof(int64_t) * (size_t)(sw->n_slices + 1)));
     SW_CHECK(hipMalloc(&sw->dict, sizeof table));
     SW_CHECK(hipMemcpyAsync(sw->dict, table, sizeof table, hipMemcpyHostToDevice, ctx->stream));
     SW_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream));
     SW_CHECK(hipMemsetAsync(slice_chunks + sw->n_slices, 0, sizeof(int32_t), ctx->stream));
-    if (A->rp64) hipLaunchKernelGGL(sw_plan_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->n_rows, R, sw_gran_cap(R), sw->hdr, slice_chunks, status);
-    else hipLaunchKernelGGL(sw_plan_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->n_rows, R, sw_gran_cap(R), sw->hdr, slice_chunks, status);
+    if (A->rp64) hipLaunchKernelGGL(sw_plan_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->n_rows, R, sw_gran_cap(R), A->view_row0, sw->hdr, slice_chunks, sw->own_rank, status);
+    else hipLaunchKernelGGL(sw_plan_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->n_rows, R, sw_gran_cap(R), A->view_row0, sw->hdr, slice_chunks, sw->own_rank, status);
     SW_CHECK(hipGetLastError());
     int h[2] = {0, 0};
     SW_CHECK(hipMemcpyAsync(h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -491,6 +780,12 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
         A->sw_state = -1;
         return BIS_OK;
     }
+    // fmt 3 first: one byte per non-zero where the matrix has few (column - row, value) pairs that run through every
+    // block's window in step with the rows
+    if (bis_opts().spmv_sellwin_pairs != 0) {
+        if (bis_status st = sw_try_pairs(ctx, A, table, pad_idx)) return st;
+        if (A->sw_state == 1 || !A->sw) return BIS_OK;
+    }
     const size_t cw = sw->fmt == 2 ? 128 : 192; // 32-bit words per chunk of 64 lanes
     SW_CHECK(hipMalloc(&sw->codes, sizeof(uint32_t) * cw * (size_t)(total + 1)));
     SW_CHECK(hipMemsetAsync(sw->codes + (size_t)total * cw, 0, sizeof(uint32_t) * cw, ctx->stream));
@@ -509,7 +804,8 @@ int bis_spmv_sellwin_format(const bis_mat *A) { return A->sw_state == 1 ? A->sw-
 // bytes of the form's own arrays one launch reads: the code stream (with its padding), block headers, slice offsets, table
 int64_t bis_spmv_sellwin_bytes(const bis_mat *A) {
     if (A->sw_state != 1) return 0;
-    return A->sw->total_chunks * (A->sw->fmt == 2 ? 512 : 768) + (int64_t)A->sw->n_blocks * 256 + 8 * (A->sw->n_slices + 1) + 2048;
+    const int64_t chunk_bytes = A->sw->fmt == 3 ? 256 : (A->sw->fmt == 2 ? 512 : 768);
+    return A->sw->total_chunks * chunk_bytes + (int64_t)A->sw->n_blocks * (256 + 2 * A->sw->pair_stride) + 8 * (A->sw->n_slices + 1) + 2048;
 }
 
 // mode 0 / 1 as in the kernel; grid and remap_arg from the caller's block map over bis_spmv_sellwin_blocks(A)
@@ -518,12 +814,23 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
     const bis_sellwin *sw = A->sw;
     const int x_al16 = ((uintptr_t)x & 15) == 0;
     const size_t win = (size_t)(2 + 8 * sw->max_gran) * 8;
+    const size_t win_off3 = (size_t)sw_layout3(sw->n_pairs, sw->diag, sw->R).win_off;
+    // diagnostic (BIS_SELLWIN_DEBUG=file): per-block cycle stamps of the last launch -- start, header arrived, barrier passed, end
+    static long long *dbg_buf = nullptr;
+    static int dbg_cap = 0;
+    long long *dbg = nullptr;
+    const char *dbg_file = getenv("BIS_SELLWIN_DEBUG");
+    if (dbg_file) {
+        if (dbg_cap < sw->n_blocks) { hipFree(dbg_buf); dbg_buf = nullptr; if (hipMalloc(&dbg_buf, sizeof(long long) * 4 * (size_t)sw->n_blocks) == hipSuccess) dbg_cap = sw->n_blocks; }
+        dbg = dbg_buf;
+    }
+    const int32_t *own = (mode == 1 && w == x + A->view_row0 && x_al16) ? sw->own_rank : nullptr; // the fused dot's w is x itself (CG: p)
 #define SW_L4(MODE, DIAG, FMT, RR)                                                                                     \
-    hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, FMT, RR>), dim3(grid), dim3(256), (SwLayout<DIAG, FMT, RR>::kWinOff) + win, \
+    hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, FMT, RR>), dim3(grid), dim3(256), (FMT == 3 ? win_off3 : (size_t)(SwLayout<DIAG, FMT, RR>::kWinOff)) + win, \
                        ctx->stream, x, y, A->n_rows, A->n_cols, sw->n_blocks, remap_arg, w, partials, stop, sw->hdr,   \
-                       sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16)
+                       sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16, sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own, dbg)
 #define SW_L3(MODE, DIAG, FMT) do { if (sw->R == 2) SW_L4(MODE, DIAG, FMT, 2); else SW_L4(MODE, DIAG, FMT, 1); } while (0)
-#define SW_L2(MODE, DIAG) do { if (sw->fmt == 2) SW_L3(MODE, DIAG, 2); else if (sw->fmt == 1) SW_L3(MODE, DIAG, 1); else SW_L3(MODE, DIAG, 0); } while (0)
+#define SW_L2(MODE, DIAG) do { if (sw->fmt == 3) SW_L3(MODE, DIAG, 3); else if (sw->fmt == 2) SW_L3(MODE, DIAG, 2); else if (sw->fmt == 1) SW_L3(MODE, DIAG, 1); else SW_L3(MODE, DIAG, 0); } while (0)
 #define SW_L1(MODE) do { if (sw->diag) SW_L2(MODE, true); else SW_L2(MODE, false); } while (0)
     if (mode == 1) SW_L1(1); else SW_L1(0);
 #undef SW_L1
@@ -531,5 +838,14 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
 #undef SW_L3
 #undef SW_L4
     BIS_HIP_CHECK(ctx, hipGetLastError());
+    if (dbg) {
+        std::vector<long long> hd((size_t)4 * sw->n_blocks);
+        BIS_HIP_CHECK(ctx, hipMemcpyAsync(hd.data(), dbg, sizeof(long long) * hd.size(), hipMemcpyDeviceToHost, ctx->stream));
+        BIS_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (FILE *f = fopen(dbg_file, "w")) {
+            for (int b = 0; b < sw->n_blocks; ++b) fprintf(f, "%lld %lld %lld %lld\n", hd[4 * b], hd[4 * b + 1], hd[4 * b + 2], hd[4 * b + 3]);
+            fclose(f);
+        }
+    }
     return BIS_OK;
 }

@@ -10,10 +10,18 @@ generated directly in HBM; inputs are resident before the timed region.
 N > 1: one process per GPU (torch.distributed.run), the matrix 1-D
 row-partitioned (z-slabs), strong scaling: the global problem is fixed.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (CRS
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the
 SpMV) with HIP events recorded on the library's stream inside the timed
-region; `cpu_baseline` times the oracle's OpenMP port of the same CG loop on
-the host cores for a bounded number of iterations (N = 1, rank 0 only).
+region, on the bytes the kernel MOVES (PMC traffic of profiles/spmv_traffic.json
+where a pass covers the kernel and its stream format, else the format's own
+bytes): a fraction of the HBM ceiling <= 1; the CRS byte count of the
+reference's loop over the same time is kept as crs_equivalent_GBs.
+`crs_value_stream` = the same loop with the 8-byte CRS values streamed (SURVEY
+8d's "CRS SpMV"), `target_512` = both at the north-star size, `config5_spmv` =
+the unstructured stand-in's SpMV; `cpu_baseline` (+ `cpu_baseline_socket`)
+time the reference's own CG (oracle/_ref) on the host cores for a bounded
+number of iterations, and `parity_max_dr_over_r0` compares a GPU run of the
+same length with that history (N = 1, rank 0 only).
 """
 import argparse
 import json
@@ -112,9 +120,11 @@ def stream_format(A):
             "streamed_bytes_per_launch": A.spmv_streamed_bytes()}
 
 
-def load_traffic(path, size, kernel):
+def load_traffic(path, size, kernel, streamed):
     """Per-launch HBM bytes of `kernel` from the rocprofv3 PMC passes of this command (tools/pmc_traffic.py writes
-    the file from separate FETCH_SIZE / WRITE_SIZE runs); None when no pass covers this kernel at this size."""
+    the file from separate FETCH_SIZE / WRITE_SIZE runs); None when no pass covers this kernel at this size -- or
+    when the measured bytes are not those of the stream format running now (a kernel name covers several formats:
+    a pass is accepted between 0.9x and 1.6x the format's own bytes)."""
     try:
         tj = json.load(open(path))
     except Exception:
@@ -123,8 +133,12 @@ def load_traffic(path, size, kernel):
         return None
     if "kernels" in tj:
         k = tj["kernels"].get(kernel)
-        return k.get("hbm_bytes_per_launch") if k else None
-    return tj.get("hbm_bytes_per_launch") if tj.get("kernel", "spmv_rowblock_kernel") == kernel else None
+        t = k.get("hbm_bytes_per_launch") if k else None
+    else:
+        t = tj.get("hbm_bytes_per_launch") if tj.get("kernel", "spmv_rowblock_kernel") == kernel else None
+    if t is None or not 0.9 * streamed <= t <= 1.6 * streamed:
+        return None
+    return t
 
 
 def spmv_roofline(A, avg_s, launches, traffic_path, size):
@@ -136,7 +150,7 @@ def spmv_roofline(A, avg_s, launches, traffic_path, size):
     fmt = stream_format(A)
     N, nnz = A.n_rows, A.nnz
     crs_bytes = 12 * nnz + (24 if A.rp_width == 8 else 20) * N
-    traffic = load_traffic(traffic_path, size, fmt["kernel"])
+    traffic = load_traffic(traffic_path, size, fmt["kernel"], fmt["streamed_bytes_per_launch"])
     moved = traffic if traffic else fmt["streamed_bytes_per_launch"]
     achieved = moved / avg_s / 1e9
     return {"bound": "hbm", "kernel": fmt["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -49,9 +49,10 @@ def test_rccl_negotiation_is_collective(world):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,kind,size", [(2, "hpcg", 12), (3, "anderson", 7), (1, "hpcg", 8),
-                                             # more ranks on the one GPU (the box allows six GPU processes): plane-aligned
-                                             # HPCG slabs and the periodic Anderson chain with its wrap-around neighbour
-                                             (4, "hpcg", 8), (5, "anderson", 5)])
+                                             # four ranks on the one GPU (the box allows six GPU processes, this runner and the
+                                             # launcher included): plane-aligned HPCG slabs and the periodic Anderson chain with
+                                             # its wrap-around neighbour, closed-form halo / interior counts (tests/dist_worker.py)
+                                             (4, "hpcg", 8), (4, "anderson", 8)])
 def test_partitioned_cg_hip(world, kind, size):
     launch(world, "gpu", kind, size)
 

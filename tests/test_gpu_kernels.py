@@ -1273,25 +1273,36 @@ def _banded_few_values(rng, n, n_values, offsets, max_len, ragged=4, empty_every
     return CRS(n, rp, col, val, n_cols=n_cols)
 
 
-@pytest.mark.parametrize("rp64,rows,joint", [(0, 1, -1), (1, 2, -1), (0, 2, 0), (1, 1, 0)])
-def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint):
+@pytest.mark.parametrize("rp64,rows,joint,pairs", [(0, 1, -1, -1), (1, 2, -1, -1), (0, 2, -1, 0), (1, 1, -1, 0), (0, 2, 0, 0), (1, 1, 0, 0)])
+def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pairs):
     """Forms 4 / 5 of the dictionary SpMV (bis_spmv_sell.hip): the block's x entries in an LDS window, the codes per
     64-row slice in lane order with neutral padding.  y is BIT-IDENTICAL to the kernel that streams the CRS values and
     within the kernel tolerance of the oracle (kernels.hpp:22-42): stencils, banded matrices with several column runs,
     ragged and empty rows, -0.0 / denormal / huge values and -0.0 row sums (the padding must not turn them into +0.0),
     dictionaries of <= 32 and of up to 255 values, the per-row diagonal form, odd sizes (a window granule that reaches
     past the last column), an x that is only 8-byte aligned, 64-bit row pointers; blocks of 256 and of 512 rows
-    (option spmv_sellwin_rows); the 16-bit joint codes (tables of at most 8 entries) and the 12-byte chunks in their
-    place (spmv_sellwin_joint 0); matrices that do not qualify (256 values: no free code for the padding; scattered
+    (option spmv_sellwin_rows); the one-byte (column - row, value) pair codes of stencil matrices (at most 253 pairs,
+    each running through every block's window in step with the rows; a pair with a gap in its run inside a block, or
+    too many pairs, takes the next format: spmv_sellwin_pairs 0 forces that), the 16-bit joint codes (tables of at most
+    8 entries) and the 12-byte chunks in their place (spmv_sellwin_joint 0); matrices that do not qualify (256 values: no free code for the padding; scattered
     columns; mostly-padding rows) keep the gather forms."""
     rng = np.random.default_rng(90 + rp64)
     ctx.set_option("force_rp64", rp64)
     ctx.set_option("spmv_sellwin_rows", rows)
     ctx.set_option("spmv_sellwin_joint", joint)
+    ctx.set_option("spmv_sellwin_pairs", pairs)
     offs_band = np.arange(-40, 41)
     offs_runs = np.concatenate([np.arange(-3, 4), np.arange(-3, 4) + 700, np.arange(-3, 4) - 700, np.arange(-3, 4) + 5000, np.arange(-3, 4) - 5000])
     neg0 = CRS(300, np.arange(0, 301 * 3, 3), np.repeat(np.arange(300), 3).astype(np.int32), np.tile([-0.0, 0.0, -0.0], 300))
     neg0.val[::3] = -1.0  # rows: -1*x + 0*x + -0*x
+    # few pairs, but the pair (column - row = 1000) exists only for rows whose index mod 256 is < 100 or >= 200: its
+    # columns leave a gap in the window of every block, slot != base + row
+    ng = 6000
+    has = (np.arange(ng) % 256 < 100) | (np.arange(ng) % 256 >= 200)
+    g_len = 3 + has.astype(np.int64)
+    g_rp = np.concatenate([[0], np.cumsum(g_len)])
+    g_col = np.concatenate([np.clip(np.array([r - 1, r, r + 1] + ([r + 1000] if has[r] else [])), 0, ng - 1) for r in range(ng)]).astype(np.int32)
+    gap = CRS(ng, g_rp, g_col, np.where(g_col == np.repeat(np.arange(ng), g_len), 4.0, -1.0))
     try:
         cases = [("hpcg 12x10x9", oracle.gen_hpcg(12, 10, 9), 4), ("hpcg 20", oracle.gen_hpcg(20), 4),
                  ("anderson W=0", oracle.gen_anderson(9, W=0.0, shift=7.0), 4),
@@ -1308,7 +1319,7 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint):
                  ("long rows", _banded_few_values(rng, 2000, 6, np.arange(-100, 101), 70, huge=False), 4),
                  ("mostly padding", _banded_few_values(rng, 40000, 6, offs_band, 30, ragged=30), 2),
                  ("scattered", _few_values_matrix(rng, 9000, 12), None),
-                 ("-0.0 sums", neg0, 4), ("one row", CRS(1, [0, 2], [0, 0], [2.0, 3.0]), 4)]
+                 ("-0.0 sums", neg0, 4), ("one row", CRS(1, [0, 2], [0, 0], [2.0, 3.0]), 4), ("gap in a pair's run", gap, 4)]
         for name, A, want in cases:
             x = rng.uniform(-1, 1, A.n_cols)
             if name == "-0.0 sums":
@@ -1321,9 +1332,15 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint):
                 info = dA.spmv_stream_info()
                 if mode == -1 and want is not None:
                     assert info[3] == want, (name, info)
-                    if want >= 4:  # 2 streamed bytes per non-zero with the joint codes, 3 otherwise
-                        few = A.nnz > 0 and len(np.unique(A.val.view(np.uint64))) <= 6 and joint != 0 and want == 4
-                        assert info[1] in ((0,) if few else (0, 1)), (name, info)
+                    if want >= 4:  # streamed bytes per non-zero: 1 with the pair codes, 2 with the joint codes, 3 otherwise
+                        stencil = name.startswith(("hpcg", "anderson", "-0.0", "one row"))
+                        few = A.nnz > 0 and len(np.unique(A.val.view(np.uint64))) <= 6 and want == 4
+                        if stencil and pairs != 0:
+                            assert info[:2] == (1, 0), (name, info)
+                        elif (few and joint != 0) or (name.startswith("anderson") and joint != 0):
+                            assert info[:2] == (2, 0), (name, info)
+                        if name.startswith("gap"):
+                            assert info[0] == 2, (name, info)
                 if mode == -1 and "random diagonal" in name:
                     assert info[3] in (5, 3, 0), (name, info)
                 dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
@@ -1348,6 +1365,7 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint):
         ctx.set_option("force_rp64", -1)
         ctx.set_option("spmv_sellwin_rows", -1)
         ctx.set_option("spmv_sellwin_joint", -1)
+        ctx.set_option("spmv_sellwin_pairs", -1)
 
 
 @pytest.mark.parametrize("rows", [1, 2])
