@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <numeric>
+#include <type_traits>
 #include <rocprim/rocprim.hpp>
 
 struct bis_trsv_tiled {
@@ -65,8 +66,7 @@ constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + p
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
 // LDS budget of a workgroup, two instantiations: LEAN (19 KiB: 8 workgroups = 32 waves per CU; rows of up to 8 entries --
 // the more tiles are resident, the more of them have their start-up loads behind them when their operands arrive) and
-// WIDE (38 KiB: 4 per CU; longer rows need room for a step's entries).  Round 3: rows of up to 16 entries take LEAN too (the plan cuts
-// its steps to the quad ring it is given): HPCG-256 3.13 -> 2.72 ms per sweep, same bits.
+// WIDE (38 KiB: 4 per CU; longer rows need room for a step's entries); lean_budget() below chooses.
 template <int OWN, int EXT, int WINDOW, int RINGQ, int RINGSLOT, int QCHUNK, int SCHUNK>
 struct TiledCfg {
     static constexpr int kOwn = OWN;         // LDS ring of the tile's own results, by slot: an in-tile operand must have been
@@ -83,7 +83,13 @@ struct TiledCfg {
 using CfgLean = TiledCfg<512, 512, 128, 128, 256, 64, 128>;
 using CfgWide = TiledCfg<1024, 1024, 256, 256, 512, 128, 256>;
 constexpr int kMaxB = 32768;      // rows per tile at most
-constexpr int kLeanMaxLen = 16;   // rows of at most this many entries take the LEAN budget (option trsv_tile_lean)
+// Rows of at most 8 entries take the LEAN budget; rows of up to 16 too on large matrices, where the sweep is bound by the number
+// of tiles in flight (HPCG-256: 3.18 -> 2.69 ms per sweep) -- on small ones the shorter steps the smaller quad ring forces cost
+// more than the residency gains (HPCG-64 0.53 -> 0.70, HPCG-128 1.01 -> 1.09 ms).  Option trsv_tile_lean overrides the length.
+inline bool lean_budget(int max_len, int64_t n) {
+    if (bis_opts().trsv_tile_lean >= 0) return max_len <= bis_opts().trsv_tile_lean;
+    return max_len <= 8 || (max_len <= 16 && n >= ((int64_t)1 << 22));
+}
 constexpr int kPollBlock = 128;   // external ordinals the poller has in flight (2 per lane); its watermark moves with the leading delivered ordinal
 constexpr unsigned kSpinLds = 1u << 26;  // polls of an LDS word before a wave gives up (several seconds: longer than the poller's budget below)
 constexpr unsigned kSpinMem = 1u << 20;  // polls of a memory word (about a second)
@@ -156,14 +162,19 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
     // comes from): [0, kOwn) ring of the tile's own results by slot, [kOwn, kOwn + kExt) ring of the external operands
     // by ordinal, then the zero slot.
     __shared__ unsigned long long opnd[kOpnd];
-    __shared__ int4 ring_code[kRingQ];
-    __shared__ double2 ring_val[2 * kRingQ];
+    __shared__ int4 ring_code[kRingQ + 1];       // (+ one permanent quad of padding entries, see the compute wave)
+    __shared__ double2 ring_val[2 * kRingQ + 2];
     __shared__ int ring_row[kRingSlot];
     __shared__ double2 ring_bD[kRingSlot];
     __shared__ unsigned ctl[C_N];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (a.stop && a.stop[1]) return;
-    if (threadIdx.x == 0) opnd[kZeroSlot] = 0ull;
+    if (threadIdx.x == 0) {
+        opnd[kZeroSlot] = 0ull;
+        ring_code[kRingQ] = make_int4(kZeroSlot, kZeroSlot, kZeroSlot, kZeroSlot);
+        ring_val[2 * kRingQ] = make_double2(0.0, 0.0);
+        ring_val[2 * kRingQ + 1] = make_double2(0.0, 0.0);
+    }
     for (;;) {
         if (threadIdx.x == 0) ctl[C_TICKET] = atomicAdd(a.ticket, 1u);
         if (threadIdx.x >= 1 && threadIdx.x < C_N) ctl[threadIdx.x] = threadIdx.x == C_EXT_SAFE ? (unsigned)(-kExtWindow) : 0u;
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             int4 p_cur = d_cur; // the following batch of 64 step descriptors, fetched a batch ahead
             int q_loaded = 0, slot_loaded = 0, ext_wm = 0; // cached watermarks
             int ext_prev = 0;
+            const long long c_first = DBG ? (long long)__builtin_readcyclecounter() : 0; // (descriptors are here: the steps begin)
             for (int s = 0; s < n_steps; ++s) {
                 const int j = s & 63;
                 if (j == 0) {
@@ -235,15 +247,41 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 const double2 bd = ring_bD[sl];
                 double acc = 0.0;
                 int qi = quad_b + wl;
-                for (int g = 0; g < nq; ++g, qi += w) {
-                    const int4 c = ring_code[qi & (kRingQ - 1)];
-                    const double2 v01 = ring_val[2 * (qi & (kRingQ - 1))], v23 = ring_val[2 * (qi & (kRingQ - 1)) + 1];
-                    const unsigned long long x0 = lds_word(&opnd[c.x]), x1 = lds_word(&opnd[c.y]), x2 = lds_word(&opnd[c.z]), x3 = lds_word(&opnd[c.w]);
-                    acc = fma(v01.x, __longlong_as_double((long long)x0), acc);
-                    acc = fma(v01.y, __longlong_as_double((long long)x1), acc);
-                    acc = fma(v23.x, __longlong_as_double((long long)x2), acc);
-                    acc = fma(v23.y, __longlong_as_double((long long)x3), acc);
-                }
+                // A step is a chain of LDS round trips -- a quad's codes, then its operands -- with the step's whole duration
+                // on the sweep's critical path (measured, tools/trsv_tile_debug.py: the sweep is the sum over the three tile
+                // directions of tiles x (steps to the face x step time + hand-off)).  The quads of a row are therefore taken
+                // G at a time: all their codes and values in ONE round trip, all their operands in a second one, then the
+                // fma chain in CRS order as before.  Rows of fewer quads read the permanent padding quad (operand 0.0,
+                // value 0.0: fma(0, 0, acc) as for the padding inside a quad).
+                auto group = [&](auto gtag, int g_left) {
+                    constexpr int G = decltype(gtag)::value;
+                    int4 c[G];
+                    double2 va[G], vb[G];
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        const int qq = u < g_left ? ((qi + u * w) & (kRingQ - 1)) : kRingQ;
+                        c[u] = ring_code[qq];
+                        va[u] = ring_val[2 * qq];
+                        vb[u] = ring_val[2 * qq + 1];
+                    }
+                    unsigned long long xo[G][4];
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        xo[u][0] = lds_word(&opnd[c[u].x]); xo[u][1] = lds_word(&opnd[c[u].y]);
+                        xo[u][2] = lds_word(&opnd[c[u].z]); xo[u][3] = lds_word(&opnd[c[u].w]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        acc = fma(va[u].x, __longlong_as_double((long long)xo[u][0]), acc);
+                        acc = fma(va[u].y, __longlong_as_double((long long)xo[u][1]), acc);
+                        acc = fma(vb[u].x, __longlong_as_double((long long)xo[u][2]), acc);
+                        acc = fma(vb[u].y, __longlong_as_double((long long)xo[u][3]), acc);
+                    }
+                    qi += G * w;
+                };
+                if (nq == 1) group(std::integral_constant<int, 1>{}, 1);
+                else if (nq == 2) group(std::integral_constant<int, 2>{}, 2);
+                else for (int g = 0; g < nq; g += 4) group(std::integral_constant<int, 4>{}, nq - g);
                 const double res = (bd.x - acc) / bd.y;
                 unsigned long long out = (unsigned long long)__double_as_longlong(res);
                 if (res != res) out = kCanonNaN; // never publish the sentinel pattern
@@ -261,7 +299,8 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             }
             if (DBG && lane == 0) {
                 long long *d = a.dbg + (int64_t)t * 8;
-                d[0] = t_start; d[1] = (long long)__builtin_amdgcn_s_memrealtime(); d[2] = w_load; d[3] = w_ext; d[7] = n_steps;
+                d[0] = t_start; d[1] = (long long)__builtin_amdgcn_s_memrealtime(); d[2] = w_load; d[3] = w_ext;
+                d[7] = (long long)n_steps | (((long long)__builtin_readcyclecounter() - c_first) << 16); // steps | core cycles from the first step to the last
             }
         } else if (wave == 1) {
             // ---- quad loader: the tile's entry stream (step order, quad-major / lane-minor) into the ring; the next
@@ -416,7 +455,7 @@ static bis_status trsv_tiled_build_host(bis_ctx *ctx, const bis_mat *T, bool bac
     if (st != BIS_OK) return st;
     int max_len = 0;
     for (int64_t r = 0; r < n; ++r) max_len = std::max<int>(max_len, (int)(rp[r + 1] - rp[r]));
-    const bool lean = max_len <= (bis_opts().trsv_tile_lean >= 0 ? bis_opts().trsv_tile_lean : kLeanMaxLen); // which LDS budget the sweep will run with (TiledCfg)
+    const bool lean = lean_budget(max_len, n); // which LDS budget the sweep will run with (TiledCfg)
     const int kOwn = lean ? CfgLean::kOwn : CfgWide::kOwn, kExt = lean ? CfgLean::kExt : CfgWide::kExt;
     const int kExtWindow = lean ? CfgLean::kExtWindow : CfgWide::kExtWindow, kRingQ = lean ? CfgLean::kRingQ : CfgWide::kRingQ;
     const int kZeroSlot = kOwn + kExt;
@@ -953,7 +992,7 @@ static bis_status trsv_tiled_build_device(bis_ctx *ctx, const bis_mat *T, bool b
     if (n == 0 || T->nnz == 0 || T->nnz > (int64_t)600000000 || T->view || n >= INT32_MAX) return BIS_OK;
     if (!(T->grid[0] > 0 && T->grid[0] * T->grid[1] * T->grid[2] * T->grid[3] == n)) return BIS_OK;
     const int max_len = T->max_row_nnz;
-    const bool lean = max_len <= (bis_opts().trsv_tile_lean >= 0 ? bis_opts().trsv_tile_lean : kLeanMaxLen);
+    const bool lean = lean_budget(max_len, n);
     PlanArgs a{};
     a.kOwn = lean ? CfgLean::kOwn : CfgWide::kOwn; a.kExt = lean ? CfgLean::kExt : CfgWide::kExt;
     a.kExtWindow = lean ? CfgLean::kExtWindow : CfgWide::kExtWindow; a.kRingQ = lean ? CfgLean::kRingQ : CfgWide::kRingQ;

@@ -26,7 +26,10 @@ f = 100.0  # s_memrealtime ticks per us (100 MHz); the wait counters are core cy
 start, end = (d[:, 0] - t0) / f, (d[:, 1] - t0) / f
 print(f"tiles {len(d)}  sweep {end.max():.1f} us (first start -> last end)")
 dur = end - start
-print(f"tile duration us: mean {dur.mean():.1f} median {np.median(dur):.1f} max {dur.max():.1f}; steps/tile mean {d[:,7].mean():.1f}")
+steps, loop_cyc = d[:, 7] & 0xffff, d[:, 7] >> 16
+print(f"tile duration us: mean {dur.mean():.1f} median {np.median(dur):.1f} max {dur.max():.1f}; steps/tile mean {steps.mean():.1f}")
+work = loop_cyc - d[:, 2] - d[:, 3]
+print(f"step loop: mean {loop_cyc.mean()/2400:.1f} us/tile, of it neither waiting for loaders nor for operands {work.mean()/2400:.1f} us = {work.sum()/steps.sum():.0f} core cycles per step")
 print(f"compute wave waited for loaders: mean {d[:,2].mean()/2400:.1f} us/tile; for external operands: mean {d[:,3].mean()/2400:.1f} us/tile")
 for nm, c in (("entry loader", 4), ("slot loader", 5), ("poller", 6)):
     print(f"{nm} finished after (from tile start) mean {((d[:,c]-d[:,0])/f).mean():.1f} us")
