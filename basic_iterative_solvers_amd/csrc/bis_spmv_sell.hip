@@ -592,6 +592,11 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     if (dbg && tid == 0) { dbg[(size_t)b * 4 + 3] = (long long)__builtin_readcyclecounter() - t_start; dbg[(size_t)b * 4] = t_start; }
 }
 
+// (Measured and removed: a "chained" variant of the fmt 3 kernel in which one workgroup walks 2 / 4 / 8 consecutive blocks and
+// loads the next block's header, codes and pair bases while the current block computes, so that only a workgroup's first
+// block pays for the header trip: HPCG-256 in the CG loop 0.218 / 0.224 / 0.235 ms against 0.205 ms with one block per
+// workgroup -- 92-100 registers instead of 54 cost a resident workgroup per CU, and the header trip it hides overlaps with
+// other workgroups' work anyway.)
 bool sw_enabled() { return bis_opts().spmv_sellwin != 0; }
 
 } // namespace
