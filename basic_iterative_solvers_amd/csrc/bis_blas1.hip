@@ -309,6 +309,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_tile_lean")) o.trsv_tile_lean = value;
     else if (!strcmp(name, "dist_host_plan")) o.dist_host_plan = value;
     else if (!strcmp(name, "trsv_inject_loss")) o.trsv_inject_loss = value;
+    else if (!strcmp(name, "trsv_inject_oom")) o.trsv_inject_oom = value;
     else return BIS_ERR_INVALID;
     return BIS_OK;
 }

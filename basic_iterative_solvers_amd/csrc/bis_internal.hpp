@@ -91,6 +91,7 @@ struct bis_options {
     int spmv_sellwin_joint = -1; // 0: never the 16-bit joint (slot, value) codes
     int device_share = -1;  // k > 1: this device is shared by k processes that all run persistent grids (several ranks on one GPU in a test
                             // or rehearsal): kernels that need their whole grid resident keep to 1/k of the device
+    int trsv_inject_oom = -1;  // test hook: 1 makes the tiled sweep's device plan run out of memory
     int trsv_inject_loss = -1; // test hook: k > 0 makes row k-1 of the next natural-order sweep wait for a result nobody publishes
 };
 // row_ptr width of a new matrix: int64 when the non-zeros (plus the stream padding) do not fit int32

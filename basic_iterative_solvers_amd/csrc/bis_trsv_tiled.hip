@@ -976,6 +976,7 @@ struct DevBufs { // scratch of the device plan, freed on every way out
     hipError_t e = hipSuccess;
     template <class T> T *get(size_t count) {
         void *p = nullptr;
+        if (e == hipSuccess && bis_opts().trsv_inject_oom > 0) e = hipErrorOutOfMemory; // test hook: the plan's scratch does not fit
         if (e == hipSuccess) e = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16));
         if (e == hipSuccess) v.push_back(p); else p = nullptr;
         return (T *)p;
@@ -1010,7 +1011,14 @@ static bis_status trsv_tiled_build_device(bis_ctx *ctx, const bis_mat *T, bool b
     hipStream_t s = ctx->stream;
     DevBufs B;
     const int grid_n = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->n_cus * 16);
-    auto fail = [&](hipError_t e) { ctx->err = std::string("tiled sptrsv plan: ") + hipGetErrorString(e); return BIS_ERR_HIP; };
+    // The plan is an optimisation: when the device cannot hold its scratch (two open-addressing tables of 4 E words, the
+    // sort buffers) it is "not applicable" -- *out stays null, the error state is cleared and the caller keeps the
+    // level-scheduled sweep -- not a failed solve.  (DevBufs and the guard below free what was allocated.)
+    auto fail = [&](hipError_t e) {
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); *out = nullptr; return BIS_OK; }
+        ctx->err = std::string("tiled sptrsv plan: ") + hipGetErrorString(e);
+        return BIS_ERR_HIP;
+    };
 #define PLAN_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_); } while (0)
 #define PLAN_RP(kernel, grid, block, ...) do { \
         if (T->rp64) hipLaunchKernelGGL((kernel<int64_t>), dim3(grid), dim3(block), 0, s, __VA_ARGS__); \

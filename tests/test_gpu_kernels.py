@@ -793,6 +793,33 @@ def test_stationary_device_schedules(ctx, oracle, kind, mat):
     st.free()
 
 
+def test_tiled_plan_out_of_memory_is_not_an_error(ctx, oracle, capfd, monkeypatch):
+    """The tiled sweep's plan is an optimisation with sizeable scratch (two hash tables of 4 E words): when the device
+    cannot hold it (test hook `trsv_inject_oom`) the solve must not fail -- the plan is 'not applicable', the error state
+    is cleared and the level-scheduled sweep computes the same bits (kernels.hpp:54-107)."""
+    A = oracle.gen_hpcg(20)
+    n = A.n_rows
+    L, Ls, U, Us = oracle.split_LU(A)
+    D, _, _ = oracle.peel_diag(L)
+    b = np.random.default_rng(31).uniform(-1, 1, n)
+    monkeypatch.setenv("BIS_TRSV_TILE_STATS", "1")
+    ctx.set_option("trsv_inject_oom", 1)
+    try:
+        dLs, dUs, dD, dDinv = ctx.split_strict(ctx.gen_hpcg(20))
+        db, x = ctx.upload(b), ctx.alloc(n)
+        capfd.readouterr()
+        ctx.sptrsv(dLs, x, dD, db)
+        assert np.array_equal(x.to_host(), oracle.sptrsv(Ls, D, b))
+        ctx.bsptrsv(dUs, x, dD, db)
+        assert np.array_equal(x.to_host(), oracle.sptrsv(Us, D, b, backward=True))
+        ctx.sync()
+        assert not [l for l in capfd.readouterr().err.splitlines() if l.startswith("tiled sptrsv plan")]  # no tiled plan was made
+    finally:
+        ctx.set_option("trsv_inject_oom", -1)
+    ctx.sptrsv(dLs, x, dD, db)  # the matrix keeps its level-scheduled sweep
+    assert np.array_equal(x.to_host(), oracle.sptrsv(Ls, D, b))
+
+
 def test_sweep_plans_follow_values_changed_in_place(ctx, oracle):
     """The tiled sweep's plan holds a copy of the triangle's values in its entry stream, row views of the level plans
     hold dictionaries: after the values change in place (written through bis_mat_debug_ptrs, then bis_mat_retune --
