@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
         long long w_load = 0, w_ext = 0;
 
         if (wave == 0) {
+            __builtin_amdgcn_s_setprio(3); // the step chain is the sweep's critical path: issue before the helper waves that share the SIMD
             // ---- compute wave: one lane per row of the step, CRS-order fma chain.  What counts is the number of wave
             // instructions per step: no predication (lanes beyond the step's rows read valid LDS and are masked at the
             // stores only), padding entries multiply 0 by the zero slot, readiness is three watermarks (the two loaders',
