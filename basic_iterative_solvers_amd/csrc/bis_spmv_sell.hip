@@ -597,6 +597,14 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
 // block pays for the header trip: HPCG-256 in the CG loop 0.218 / 0.224 / 0.235 ms against 0.205 ms with one block per
 // workgroup -- 92-100 registers instead of 54 cost a resident workgroup per CU, and the header trip it hides overlaps with
 // other workgroups' work anyway.)
+// (Also measured and removed: a double-buffered, software-pipelined variant -- a workgroup walks 4 / 8 / 16 consecutive blocks
+// with TWO window buffers in LDS; while block i computes, the window loads of block i + 1 (LDS-DMA issued as an asm statement
+// so that hipcc does not drain it in front of the computation's first LDS read; __builtin_amdgcn_s_waitcnt at the top of each
+// step so that it knows the computing set's registers are ready) and the header / codes of block i + 2 are in flight; three
+// register sets rotate by a three-fold unroll, no copies.  The ISA shows exactly the intended overlap and the results are
+// bit-identical, but HPCG-256 in the CG loop takes 0.271 / 0.275 / 0.278 ms against 0.206: twice the LDS per workgroup
+// leaves three workgroups = three waves per SIMD, and the computation -- two dependent LDS round trips per four non-zeros
+// -- needs the six waves per SIMD of the single-buffer kernel to cover its own LDS latency.)
 bool sw_enabled() { return bis_opts().spmv_sellwin != 0; }
 
 } // namespace
