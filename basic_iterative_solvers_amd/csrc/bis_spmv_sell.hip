@@ -51,6 +51,7 @@ struct bis_sellwin {
     int fmt = 0;                     // 0: 12-byte chunks, value byte = table index; 1: value byte = 8 * index (<= 32 entries);
                                      // 2: 8-byte chunks, 16-bit codes slot : 13 | index : 3 (<= 8 entries);
                                      // 3: 4-byte chunks, one byte per non-zero = index of its (column - row, value) pair
+    int uniform_chunks = 0;          // > 0: every slice has this many chunks (short slices padded up when that costs < 3 % of the stream)
     int n_pairs = 0, pair_stride = 0, diag_pair = -1; // fmt 3: pairs of the matrix, int16 words per block in blk_base, the per-row-diagonal pair
     int16_t *blk_base = nullptr;     // fmt 3: [n_blocks * pair_stride] window slot of pair e's column for the block's first row
     unsigned long long *pair_key = nullptr; // fmt 3: [256] the pairs, ascending ((uint32)(column - row) << 8 | value code)
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void sw_plan_kernel(const RP *__restrict__ row
         int len = 0;
         if (lr < rows) len = (int)((int64_t)row_ptr[r0 + lr + 1] - (int64_t)row_ptr[r0 + lr]);
         const int m = sw_wave_max(len);
-        if ((tid & 63) == 0) slice_chunks[(size_t)b * 4 * R + sl] = (m + 3) >> 2;
+        if ((tid & 63) == 0) { slice_chunks[(size_t)b * 4 * R + sl] = (m + 3) >> 2; atomicMax(&status[5], (m + 3) >> 2); }
     }
     const int64_t s = (int64_t)row_ptr[r0], e = (int64_t)row_ptr[r0 + rows];
     for (int64_t k = s + tid; k < e; k += 256) {
@@ -204,6 +205,11 @@ __global__ __launch_bounds__(256) void sw_plan_kernel(const RP *__restrict__ row
         hdr[(size_t)b * 64 + tid] = word;
     }
     if (tid == 0) atomicMax(&status[1], n);
+}
+
+__global__ __launch_bounds__(256) void sw_uniform_kernel(int64_t *__restrict__ chunk0, int64_t n, int64_t per) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) chunk0[i] = i * per;
 }
 
 __global__ __launch_bounds__(256) void sw_widen_kernel(const int32_t *__restrict__ in, int64_t *__restrict__ out, int64_t n) {
@@ -412,24 +418,6 @@ __host__ __device__ inline SwLayout3 sw_layout3(int n_pairs, bool diag, int R) {
     l.win_off = l.pad_off; // the window's own first slot is the -0.0 one
     return l;
 }
-// diag_code = 16 * (index of the per-row-diagonal pair), row_off = 8 * (row in block)
-template <bool DIAG, int R>
-__device__ __forceinline__ void sw_chunk_fma3(const unsigned char *lds, const sw_chunk<3> &cd, unsigned diag_rel, unsigned diag_code,
-                                              unsigned row_off, double &acc) {
-#pragma clang fp contract(off)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const unsigned ea = ((cd.a >> (8 * q)) & 0xffu) << 4;
-        const uint2 xm = *reinterpret_cast<const uint2 *>(lds + ea + 8);
-        unsigned va = ea;
-        if (DIAG) va = ea == diag_code ? diag_rel : ea;
-        const double v = *reinterpret_cast<const double *>(lds + va);
-        const double xv = *reinterpret_cast<const double *>(lds + (xm.x + (row_off & xm.y)));
-        const double pr = v * xv;
-        acc = acc + pr;
-    }
-}
-
 template <bool DIAG, int FMT, int R>
 __device__ __forceinline__ void sw_chunk_fma(const unsigned char *lds, const sw_chunk<FMT> &cd, unsigned diag_rel, double &acc) {
 #pragma clang fp contract(off)
@@ -455,18 +443,63 @@ __device__ __forceinline__ void sw_chunk_fma(const unsigned char *lds, const sw_
     }
 }
 
+// fmt 3, Q chunks of a slice, software-pipelined by hand: a non-zero costs two DEPENDENT LDS round trips (its table entry,
+// then the x slot the entry points at), and with the chunks taken one after the other a wave has only one of them in flight.
+// Here the table entries of chunk q + 1 are read before chunk q's x slots are: one round trip per chunk instead of two.
+struct sw_ent { double v; unsigned xo, mask; };
+template <bool DIAG>
+__device__ __forceinline__ void sw_read_ents(const unsigned char *lds, unsigned word, unsigned diag_rel, unsigned diag_code, sw_ent (&e)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned ea = ((word >> (8 * q)) & 0xffu) << 4;
+        const uint2 xm = *reinterpret_cast<const uint2 *>(lds + ea + 8);
+        unsigned va = ea;
+        if (DIAG) va = ea == diag_code ? diag_rel : ea;
+        e[q].v = *reinterpret_cast<const double *>(lds + va);
+        e[q].xo = xm.x;
+        e[q].mask = xm.y;
+    }
+}
+template <int Q, bool DIAG, int R>
+__device__ __forceinline__ void sw_consume3(const unsigned char *lds, const sw_chunk<3> (&cd)[8], unsigned diag_rel, unsigned diag_code,
+                                            unsigned row_off, double &acc) {
+#pragma clang fp contract(off)
+    sw_ent cur[4], nxt[4];
+    sw_read_ents<DIAG>(lds, cd[0].a, diag_rel, diag_code, cur);
+#pragma unroll
+    for (int c = 0; c < Q; ++c) {
+        double xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const double *>(lds + (cur[q].xo + (row_off & cur[q].mask)));
+        if (c + 1 < Q) sw_read_ents<DIAG>(lds, cd[c + 1].a, diag_rel, diag_code, nxt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double pr = cur[q].v * xv[q];
+            acc = acc + pr;
+        }
+        if (c + 1 < Q) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        }
+    }
+}
+
 template <int Q, bool DIAG, int FMT, int R>
 __device__ __forceinline__ void sw_consume(const unsigned char *lds, const sw_chunk<FMT> (&cd)[8], unsigned diag_rel, unsigned diag_code,
                                            unsigned row_off, double &acc) {
+    if constexpr (FMT == 3) {
+        sw_consume3<Q, DIAG, R>(lds, cd, diag_rel, diag_code, row_off, acc);
+    } else {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        if constexpr (FMT == 3) sw_chunk_fma3<DIAG, R>(lds, cd[q], diag_rel, diag_code, row_off, acc);
-        else sw_chunk_fma<DIAG, FMT, R>(lds, cd[q], diag_rel, acc);
+        for (int q = 0; q < Q; ++q) sw_chunk_fma<DIAG, FMT, R>(lds, cd[q], diag_rel, acc);
     }
 }
 
 // MODE 0: y = A x.  MODE 1: also partials[slice] = sum over the slice's rows of y[r] w[r] (CG's (Ap, p)).
-template <int MODE, bool DIAG, int FMT, int R>
+// NCH > 0: every slice of the matrix has exactly NCH chunks (sw->uniform_chunks; fmt 3 only): the chunk walk is straight-line
+// code, which is what lets the hand-pipelined LDS reads of sw_consume3 overlap (a walk that can end after any chunk is a chain
+// of branches, and the compiler keeps each chunk's reads behind the branch before it).
+template <int MODE, bool DIAG, int FMT, int R, int NCH = 0>
 __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
     double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
@@ -492,8 +525,13 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     double wr[R], dval[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        c0[r] = slice_chunk0[slice0 + r];
-        nch[r] = (int)(slice_chunk0[slice0 + r + 1] - c0[r]);
+        if constexpr (NCH > 0) {
+            c0[r] = (slice0 + r) * NCH;
+            nch[r] = NCH;
+        } else {
+            c0[r] = slice_chunk0[slice0 + r];
+            nch[r] = (int)(slice_chunk0[slice0 + r + 1] - c0[r]);
+        }
         const Chunk *cp = reinterpret_cast<const Chunk *>(codes) + (size_t)c0[r] * 64 + lane;
         const int last = max(nch[r] - 1, 0); // (the stream ends with one spare chunk: an empty last slice reads it)
 #pragma unroll
@@ -564,6 +602,8 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
         const unsigned row_off = (unsigned)(((wv * R + r) * 64 + lane) * 8), diag_code = (unsigned)diag_pair << 4;
         const Chunk *cp = reinterpret_cast<const Chunk *>(codes) + (size_t)c0[r] * 64 + lane;
         double acc = 0.0;
+        if constexpr (NCH > 0) sw_consume<NCH, DIAG, FMT, R>(lds, cd[r], diag_rel, diag_code, row_off, acc);
+        else
         for (int cb = 0; cb < nch[r]; cb += 8) {
             const int rem = nch[r] - cb;
             if (cb > 0) {
@@ -768,12 +808,14 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     SW_CHECK(hipMalloc(&sw->dict, sizeof table));
     SW_CHECK(hipMemcpyAsync(sw->dict, table, sizeof table, hipMemcpyHostToDevice, ctx->stream));
     SW_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream));
+    SW_CHECK(hipMemsetAsync(status + 5, 0, sizeof(int), ctx->stream)); // most chunks of a slice
     SW_CHECK(hipMemsetAsync(slice_chunks + sw->n_slices, 0, sizeof(int32_t), ctx->stream));
     if (A->rp64) hipLaunchKernelGGL(sw_plan_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->n_rows, R, sw_gran_cap(R), A->view_row0, sw->hdr, slice_chunks, sw->own_rank, status);
     else hipLaunchKernelGGL(sw_plan_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->n_rows, R, sw_gran_cap(R), A->view_row0, sw->hdr, slice_chunks, sw->own_rank, status);
     SW_CHECK(hipGetLastError());
-    int h[2] = {0, 0};
+    int h[2] = {0, 0}, h_maxch = 0;
     SW_CHECK(hipMemcpyAsync(h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    SW_CHECK(hipMemcpyAsync(&h_maxch, status + 5, sizeof h_maxch, hipMemcpyDeviceToHost, ctx->stream));
     // chunk offsets of the slices
     const int64_t ns1 = sw->n_slices + 1;
     hipLaunchKernelGGL(sw_widen_kernel, dim3((unsigned)((ns1 + 255) / 256)), dim3(256), 0, ctx->stream, slice_chunks, sw->slice_chunk0, ns1);
@@ -787,6 +829,14 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     SW_CHECK(hipStreamSynchronize(ctx->stream)); // table[], h, total
     hipFree(tmp); tmp = nullptr;
     hipFree(slice_chunks); slice_chunks = nullptr;
+    // Every slice the same number of chunks where padding the short ones up costs < 3 % (a stencil: only the slices on the grid's
+    // faces are shorter): the SpMV then walks a compile-time number of chunks
+    if (h_maxch > 0 && h_maxch <= 8 && !h[0] && (double)h_maxch * (double)sw->n_slices <= 1.03 * (double)total) {
+        hipLaunchKernelGGL(sw_uniform_kernel, dim3((unsigned)((ns1 + 255) / 256)), dim3(256), 0, ctx->stream, sw->slice_chunk0, ns1, (int64_t)h_maxch);
+        SW_CHECK(hipGetLastError());
+        total = (int64_t)h_maxch * sw->n_slices;
+        sw->uniform_chunks = h_maxch;
+    }
     sw->total_chunks = total;
     sw->max_gran = h[1];
     // not representable, or more than 30 % of padding (ragged rows): the gather kernels stay
@@ -844,7 +894,14 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
     hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, FMT, RR>), dim3(grid), dim3(256), (FMT == 3 ? win_off3 : (size_t)(SwLayout<DIAG, FMT, RR>::kWinOff)) + win, \
                        ctx->stream, x, y, A->n_rows, A->n_cols, sw->n_blocks, remap_arg, w, partials, stop, sw->hdr,   \
                        sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16, sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own, dbg)
-#define SW_L3(MODE, DIAG, FMT) do { if (sw->R == 2) SW_L4(MODE, DIAG, FMT, 2); else SW_L4(MODE, DIAG, FMT, 1); } while (0)
+#define SW_L4N(MODE, DIAG, RR, NN)                                                                                      \
+    hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, 3, RR, NN>), dim3(grid), dim3(256), win_off3 + win,             \
+                       ctx->stream, x, y, A->n_rows, A->n_cols, sw->n_blocks, remap_arg, w, partials, stop, sw->hdr,   \
+                       sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16, sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own, dbg)
+#define SW_L3(MODE, DIAG, FMT) do {                                                                                    \
+        if (FMT == 3 && sw->uniform_chunks == 7 && sw->R == 2) SW_L4N(MODE, DIAG, 2, 7);                               \
+        else if (FMT == 3 && sw->uniform_chunks == 2 && sw->R == 2) SW_L4N(MODE, DIAG, 2, 2);                          \
+        else if (sw->R == 2) SW_L4(MODE, DIAG, FMT, 2); else SW_L4(MODE, DIAG, FMT, 1); } while (0)
 #define SW_L2(MODE, DIAG) do { if (sw->fmt == 3) SW_L3(MODE, DIAG, 3); else if (sw->fmt == 2) SW_L3(MODE, DIAG, 2); else if (sw->fmt == 1) SW_L3(MODE, DIAG, 1); else SW_L3(MODE, DIAG, 0); } while (0)
 #define SW_L1(MODE) do { if (sw->diag) SW_L2(MODE, true); else SW_L2(MODE, false); } while (0)
     if (mode == 1) SW_L1(1); else SW_L1(0);
@@ -852,6 +909,7 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
 #undef SW_L2
 #undef SW_L3
 #undef SW_L4
+#undef SW_L4N
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (dbg) {
         std::vector<long long> hd((size_t)4 * sw->n_blocks);
