@@ -5,6 +5,7 @@ Jacobi-preconditioned CG, row-partitioned): shift 0 is the config as named (inde
 timing workload), shift 9 its conditioned twin with the r0 check."""
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -48,6 +49,11 @@ def run_distributed(args, rank, world, local_rank):
     from .launcher import even_row_starts, route_send_lists, setup_rccl, torch_comm_ops
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # stdout carries ONE JSON line (bench.py's contract): the banners RCCL and gloo print from C at start-up ("RCCL version :
+    # ...", "[Gloo] Rank 0 is connected ...") go to stderr -- file descriptor 1 points at stderr until the record is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     # BIS_BENCH_REHEARSE=1 (tests on a one-GPU box): every rank uses cuda:0, gloo process group,
     # torch.distributed transport through the C-ABI callbacks -- everything of this function except RCCL.
     rehearse = os.environ.get("BIS_BENCH_REHEARSE") == "1"
@@ -182,7 +188,10 @@ def run_distributed(args, rank, world, local_rank):
                          "crs_algorithmic_bytes_per_launch": spmv_bytes, "crs_equivalent_GBs": spmv_bytes / spmv_avg_s / 1e9,
                          "avg_launch_ms": spmv_avg_s * 1e3, "launches": launches},
         }
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     cg.free()
     td.barrier()
     d.free()
