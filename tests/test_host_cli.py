@@ -332,3 +332,34 @@ def test_cli_grid_hint_and_trsv_modes(tmp_path, oracle, monkeypatch, solver, pc)
     auto, n_auto, n_auto_dev = run(mtx2, [])
     lvl, n_lvl, _ = run(mtx2, ["-trsv", "level"])
     assert len(auto) > 3 and auto == lvl and n_auto >= 1 and n_auto_dev == n_auto and n_lvl == 0
+
+
+def test_cli_mid_size_mtx_file_equals_generator_and_reference(tmp_path, oracle):
+    """The `.mtx` input path at a size where it matters (sparse_matrix.hpp:225-357: 830 584 entries, 17 MB of text, the
+    threaded reader): HPCG-32 written as a general MatrixMarket file with its ROWS in shuffled order (entries of a row
+    stay in ascending column order -- the reference's reader keeps the file's order inside a row) gives the same CRS,
+    hence the same residual table digit for digit as the generator input `hpcg:32`, and the reference's own history
+    (tests/golden/histories_mid.json, `hpcg32|sgs`) to 1e-10 r0; the binary CRS cache written on the way reproduces it."""
+    A = oracle.gen_hpcg(32)
+    rng = np.random.default_rng(6)
+    order = rng.permutation(A.n_rows)
+    lens = np.diff(A.row_ptr)
+    idx = np.concatenate([np.arange(A.row_ptr[r], A.row_ptr[r + 1]) for r in order])
+    rows = np.repeat(order, lens[order])
+    mtx = str(tmp_path / "HPCG-32.mtx")
+    with open(mtx, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%% rows in shuffled order\n%d %d %d\n" % (A.n_rows, A.n_rows, A.nnz))
+        np.savetxt(f, np.column_stack([rows + 1, A.col[idx] + 1, A.val[idx]]), fmt="%d %d %.17g")
+
+    def run(matrix, extra=()):
+        out = subprocess.run([BIN, matrix, "-sgs"] + list(extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return [float(v) for _, v in RES.findall(out.stdout)]
+
+    gen = run("hpcg:32")
+    cache = str(tmp_path / "hpcg32.crs")
+    from_file = run(mtx, ["-cache", cache])
+    assert len(gen) > 100 and from_file == gen
+    assert os.path.exists(cache) and run(mtx, ["-cache", cache]) == gen
+    e = _HM["hpcg32|sgs|none|"]
+    check_history(dict(hist=np.array(from_file), iters=len(from_file) - 1, converged=True), e, "sgs")
