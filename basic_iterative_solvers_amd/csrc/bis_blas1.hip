@@ -266,6 +266,7 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_TRSV_TILE_WGS")) v.trsv_tile_wgs = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_EDGE")) v.trsv_tile_edge = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_LEAN")) v.trsv_tile_lean = atoi(e);
+        if (const char *e = getenv("BIS_TRSV_TILE_EXP")) v.trsv_tile_exp = atoi(e);
         return v;
     }();
     return o;
@@ -307,6 +308,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_tile_wgs")) o.trsv_tile_wgs = value;
     else if (!strcmp(name, "trsv_tile_edge")) o.trsv_tile_edge = value;
     else if (!strcmp(name, "trsv_tile_lean")) o.trsv_tile_lean = value;
+    else if (!strcmp(name, "trsv_tile_exp")) o.trsv_tile_exp = value;
     else if (!strcmp(name, "dist_host_plan")) o.dist_host_plan = value;
     else if (!strcmp(name, "trsv_inject_loss")) o.trsv_inject_loss = value;
     else if (!strcmp(name, "trsv_inject_oom")) o.trsv_inject_oom = value;

@@ -64,11 +64,14 @@ namespace {
 
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload (same as bis_sptrsv.hip)
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
-// LDS budget of a workgroup, two instantiations: LEAN (19 KiB: 8 workgroups = 32 waves per CU; rows of up to 8 entries --
-// the more tiles are resident, the more of them have their start-up loads behind them when their operands arrive) and
-// WIDE (38 KiB: 4 per CU; longer rows need room for a step's entries); lean_budget() below chooses.
-template <int OWN, int EXT, int WINDOW, int RINGQ, int RINGSLOT, int QCHUNK, int SCHUNK>
+// LDS budget of a workgroup, two instantiations: LEAN (19 KiB; rows of up to 8 entries, up to 16 on large matrices) and
+// WIDE (38 KiB; longer rows need room for a step's entries); lean_budget() below chooses.  Both run 4 workgroups per CU:
+// the kernel takes 118-132 VGPRs (forced to 64 it spills and is 2x slower; 86 with kGroup = 2 buys a fifth workgroup and
+// loses as much in the steps -- DESIGN.md section 4, second pass), so LEAN's smaller rings pay through shorter start-up,
+// not through residency.
+template <int OWN, int EXT, int WINDOW, int RINGQ, int RINGSLOT, int QCHUNK, int SCHUNK, int GROUP>
 struct TiledCfg {
+    static constexpr int kGroup = GROUP;     // quads of a row the compute wave reads together (registers: 20 per quad)
     static constexpr int kOwn = OWN;         // LDS ring of the tile's own results, by slot: an in-tile operand must have been
                                              // produced fewer than kOwn - 128 slots before its consumer, else it is fetched like an external one
     static constexpr int kExt = EXT;         // LDS ring of external operands, by ordinal (first-need order)
@@ -80,8 +83,8 @@ struct TiledCfg {
     static constexpr int kQuadChunk = QCHUNK; // quads per loader round
     static constexpr int kSlotChunk = SCHUNK; // rows per loader round
 };
-using CfgLean = TiledCfg<512, 512, 128, 128, 256, 64, 128>;
-using CfgWide = TiledCfg<1024, 1024, 256, 256, 512, 128, 256>;
+using CfgLean = TiledCfg<512, 512, 128, 128, 256, 64, 128, 4>;
+using CfgWide = TiledCfg<1024, 1024, 256, 256, 512, 128, 256, 4>;
 constexpr int kMaxB = 32768;      // rows per tile at most
 // Rows of at most 8 entries take the LEAN budget; rows of up to 16 too on large matrices, where the sweep is bound by the number
 // of tiles in flight (HPCG-256: 3.18 -> 2.69 ms per sweep) -- on small ones the shorter steps the smaller quad ring forces cost
@@ -90,7 +93,6 @@ inline bool lean_budget(int max_len, int64_t n) {
     if (bis_opts().trsv_tile_lean >= 0) return max_len <= bis_opts().trsv_tile_lean;
     return max_len <= 8 || (max_len <= 16 && n >= ((int64_t)1 << 22));
 }
-constexpr int kPollBlock = 128;   // external ordinals the poller has in flight (2 per lane); its watermark moves with the leading delivered ordinal
 constexpr unsigned kSpinLds = 1u << 26;  // polls of an LDS word before a wave gives up (several seconds: longer than the poller's budget below)
 constexpr unsigned kSpinMem = 1u << 20;  // polls of a memory word (about a second)
 
@@ -113,6 +115,17 @@ __device__ __forceinline__ void lds_release(unsigned *p, unsigned v) {
 }
 __device__ __forceinline__ unsigned long long lds_word(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int4 nt_load(const int4 *p) {
+    const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 nt_load(const double2 *p) {
+    const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p));
+    return make_double2(v.x, v.y);
 }
 
 __global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned long long *xs, int64_t n) {
@@ -144,8 +157,12 @@ struct TiledArgs {
     unsigned *fault;
     const int *stop; // a device schedule's stop flag (flags[1]): the sweep is a no-op once it is set
     int n_tiles;
-    long long *dbg; // DBG only, 8 words per tile: start, end (s_memrealtime, 100 MHz), core cycles the compute wave waited for the
+    int exp_flags;  // option trsv_tile_exp (experiments, timing only -- results are wrong): 1 no x store, 2 no xs store, 4 no b / D loads,
+                    // 8 no entry loads, 16 external operands taken as delivered, 32 tiles dealt statically instead of by ticket
+    long long *dbg; // DBG only, 16 words per tile (8, 9: the poller's rounds and the core cycles they took): start, end (s_memrealtime, 100 MHz), core cycles the compute wave waited for the
                     // loaders / for external operands, end of the quad loader / slot loader / poller, steps
+    long long *dbg_step; // DBG only: core-cycle stamps inside the steps of the middle tile, 8 per step
+    long long *dbg_pub, *dbg_del; // DBG only: s_memrealtime at which a slot's result was published / an external ordinal was delivered
 };
 
 __device__ __forceinline__ int wave_min_int(int v) {
@@ -154,8 +171,9 @@ __device__ __forceinline__ int wave_min_int(int v) {
     return v;
 }
 
-template <typename CFG, bool DBG>
+template <typename CFG, bool DBG, bool EXP = false, int kPollBlock = 128>
 __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
+    const int exp_flags = EXP ? a.exp_flags : 0; // (the timing experiments are a build of their own: nothing of them in the product's loops)
     constexpr int kOwn = CFG::kOwn, kExt = CFG::kExt, kExtWindow = CFG::kExtWindow, kZeroSlot = CFG::kZeroSlot, kOpnd = CFG::kOpnd;
     constexpr int kRingQ = CFG::kRingQ, kRingSlot = CFG::kRingSlot, kQuadChunk = CFG::kQuadChunk, kSlotChunk = CFG::kSlotChunk;
     // operands of the tile's rows, indexed directly by the entry codes (one LDS read per operand, no branch on where it
@@ -175,8 +193,14 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
         ring_val[2 * kRingQ] = make_double2(0.0, 0.0);
         ring_val[2 * kRingQ + 1] = make_double2(0.0, 0.0);
     }
+    unsigned dealt = blockIdx.x;
     for (;;) {
-        if (threadIdx.x == 0) ctl[C_TICKET] = atomicAdd(a.ticket, 1u);
+        if (threadIdx.x == 0) {
+            unsigned tt = (unsigned)a.n_tiles;
+            if (exp_flags & 32) { tt = dealt; dealt += gridDim.x; }
+            else tt = atomicAdd(a.ticket, 1u);
+            ctl[C_TICKET] = tt;
+        }
         if (threadIdx.x >= 1 && threadIdx.x < C_N) ctl[threadIdx.x] = threadIdx.x == C_EXT_SAFE ? (unsigned)(-kExtWindow) : 0u;
         __syncthreads();
         const int t = (int)ctl[C_TICKET];
@@ -191,6 +215,12 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
         const int n_ext = (int)(a.tile_ext0[t + 1] - ext0);
         const long long t_start = DBG ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
         long long w_load = 0, w_ext = 0;
+        if (DBG && lane == 0) { // where the wave sits: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SE ...) and the XCD
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            a.dbg[(int64_t)t * 16 + 10 + wave] = (long long)hw | ((long long)(xcc & 0xf) << 32);
+        }
 
         if (wave == 0) {
             __builtin_amdgcn_s_setprio(3); // the step chain is the sweep's critical path: issue before the helper waves that share the SIMD
@@ -204,7 +234,14 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             int q_loaded = 0, slot_loaded = 0, ext_wm = 0; // cached watermarks
             int ext_prev = 0;
             const long long c_first = DBG ? (long long)__builtin_readcyclecounter() : 0; // (descriptors are here: the steps begin)
+            auto stamp = [&](int s, int k) {
+                if (DBG && t == a.n_tiles / 2 && s < 64) {
+                    const long long c = (long long)__builtin_readcyclecounter();
+                    if (lane == 0) a.dbg_step[s * 8 + k] = c;
+                }
+            };
             for (int s = 0; s < n_steps; ++s) {
+                stamp(s, 0);
                 const int j = s & 63;
                 if (j == 0) {
                     if (s > 0) d_cur = p_cur;
@@ -241,6 +278,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     }
                     if (DBG) w_ext += (long long)__builtin_readcyclecounter() - t1;
                 }
+                stamp(s, 1);
                 // lanes past the step's width take the last row's slots (loaded, in range); their results are masked at the store
                 const int wl = min(lane, w - 1);
                 const int sl = (slot_b + wl) & (kRingSlot - 1);
@@ -265,12 +303,14 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                         va[u] = ring_val[2 * qq];
                         vb[u] = ring_val[2 * qq + 1];
                     }
+                    if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(s, 2); }
                     unsigned long long xo[G][4];
 #pragma unroll
                     for (int u = 0; u < G; ++u) {
                         xo[u][0] = lds_word(&opnd[c[u].x]); xo[u][1] = lds_word(&opnd[c[u].y]);
                         xo[u][2] = lds_word(&opnd[c[u].z]); xo[u][3] = lds_word(&opnd[c[u].w]);
                     }
+                    if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(s, 3); }
 #pragma unroll
                     for (int u = 0; u < G; ++u) {
                         acc = fma(va[u].x, __longlong_as_double((long long)xo[u][0]), acc);
@@ -282,15 +322,19 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 };
                 if (nq == 1) group(std::integral_constant<int, 1>{}, 1);
                 else if (nq == 2) group(std::integral_constant<int, 2>{}, 2);
-                else for (int g = 0; g < nq; g += 4) group(std::integral_constant<int, 4>{}, nq - g);
+                else for (int g = 0; g < nq; g += CFG::kGroup) group(std::integral_constant<int, CFG::kGroup>{}, nq - g);
+                if (DBG) { asm volatile("" :: "v"(acc)); stamp(s, 4); }
                 const double res = (bd.x - acc) / bd.y;
                 unsigned long long out = (unsigned long long)__double_as_longlong(res);
+                if (DBG) { asm volatile("" :: "v"(out)); stamp(s, 5); }
                 if (res != res) out = kCanonNaN; // never publish the sentinel pattern
                 if (lane < w) {
                     __hip_atomic_store(&opnd[(slot_b + lane) & (kOwn - 1)], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    a.x[row] = __longlong_as_double((long long)out);
-                    __hip_atomic_store(&a.xs[slot0 + slot_b + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(exp_flags & 1)) a.x[row] = __longlong_as_double((long long)out);
+                    if (!(exp_flags & 2)) __hip_atomic_store(&a.xs[slot0 + slot_b + lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (DBG) a.dbg_pub[slot0 + slot_b + lane] = (long long)__builtin_amdgcn_s_memrealtime();
                 }
+                stamp(s, 6);
                 if (lane == 0 && (s & 7) == 7) {
                     lds_release(&ctl[C_Q_DONE], (unsigned)quad_b);
                     lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_b);
@@ -299,7 +343,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 ext_prev = ext_end;
             }
             if (DBG && lane == 0) {
-                long long *d = a.dbg + (int64_t)t * 8;
+                long long *d = a.dbg + (int64_t)t * 16;
                 d[0] = t_start; d[1] = (long long)__builtin_amdgcn_s_memrealtime(); d[2] = w_load; d[3] = w_ext;
                 d[7] = (long long)n_steps | (((long long)__builtin_readcyclecounter() - c_first) << 16); // steps | core cycles from the first step to the last
             }
@@ -313,19 +357,24 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int64_t g = quad0 + done + min(u * 64 + lane, chunk - 1);
-                    c_n[u] = a.quad_code[g];
-                    va_n[u] = a.quad_val[2 * g];
-                    vb_n[u] = a.quad_val[2 * g + 1];
+                    // (read once: non-temporal, so the stream does not push the x / b / D lines out of the L2)
+                    c_n[u] = nt_load(&a.quad_code[g]);
+                    va_n[u] = nt_load(&a.quad_val[2 * g]);
+                    vb_n[u] = nt_load(&a.quad_val[2 * g + 1]);
                 }
             };
-            if (n_quads > 0) issue(0, min(kQuadChunk, n_quads));
+            if (exp_flags & 8) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { c_n[u] = make_int4(kZeroSlot, kZeroSlot, kZeroSlot, kZeroSlot); va_n[u] = vb_n[u] = make_double2(0.0, 0.0); }
+            }
+            if (n_quads > 0 && !(exp_flags & 8)) issue(0, min(kQuadChunk, n_quads));
             for (int done = 0; done < n_quads;) {
                 const int chunk = min(kQuadChunk, n_quads - done);
                 int4 c[U];
                 double2 va[U], vb[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) { c[u] = c_n[u]; va[u] = va_n[u]; vb[u] = vb_n[u]; }
-                if (done + chunk < n_quads) issue(done + chunk, min(kQuadChunk, n_quads - done - chunk));
+                if (done + chunk < n_quads && !(exp_flags & 8)) issue(done + chunk, min(kQuadChunk, n_quads - done - chunk));
                 unsigned spins = 0;
                 while (done + chunk - (int)lds_acquire(&ctl[C_Q_DONE]) > kRingQ) {
                     if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
@@ -344,7 +393,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 done += chunk;
                 lds_release(&ctl[C_Q_LOADED], (unsigned)done);
             }
-            if (DBG && lane == 0) a.dbg[(int64_t)t * 8 + 4] = (long long)__builtin_amdgcn_s_memrealtime();
+            if (DBG && lane == 0) a.dbg[(int64_t)t * 16 + 4] = (long long)__builtin_amdgcn_s_memrealtime();
         } else if (wave == 2) {
             // ---- per-row operand loader: row index, b[row], D[row] in slot order (rows one round ahead of their b / D) ----
             constexpr int U = kSlotChunk / 64;
@@ -358,8 +407,8 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     r[u] = r_next[u];
-                    bv[u] = a.b[r[u]];
-                    dv[u] = a.D[r[u]];
+                    bv[u] = (exp_flags & 4) ? 1.0 : a.b[r[u]];
+                    dv[u] = (exp_flags & 4) ? 2.0 : a.D[r[u]];
                 }
                 if (done + chunk < n_slots) {
 #pragma unroll
@@ -381,13 +430,15 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 done += chunk;
                 lds_release(&ctl[C_SLOT_LOADED], (unsigned)done);
             }
-            if (DBG && lane == 0) a.dbg[(int64_t)t * 8 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
+            if (DBG && lane == 0) a.dbg[(int64_t)t * 16 + 5] = (long long)__builtin_amdgcn_s_memrealtime();
         } else {
             // ---- poller: external operands in first-need order into their ring, a block of kPollBlock ordinals (8 per
             // lane, all in flight together) at a time; the watermark (all ordinals below it delivered) moves when a
             // block is complete ----
             constexpr int U = kPollBlock / 64;
             int wm_pub = 0;
+            long long rounds = 0;
+            const long long c_poll = DBG ? (long long)__builtin_readcyclecounter() : 0;
             for (int base = 0; base < n_ext; base += kPollBlock) {
                 int src[U];
                 bool got[U];
@@ -410,7 +461,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     for (int u = 0; u < U; ++u) vb[u] = got[u] ? 0ull : __hip_atomic_load(&a.xs[src[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // ... or as soon as any wait of the sweep has raised the fault word: the grid then drains at once
                     ++spins;
-                    const bool give_up = spins > kSpinMem || ((spins & 255u) == 0u && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
+                    const bool give_up = (exp_flags & 16) || spins > kSpinMem || ((spins & 255u) == 0u && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u);
                     bool all = true;
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -418,10 +469,11 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                             __hip_atomic_store(&opnd[kOwn + ((base + u * 64 + lane) & (kExt - 1))], vb[u] == kSentinel ? kCanonNaN : vb[u],
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             got[u] = true;
+                            if (DBG) a.dbg_del[ext0 + base + u * 64 + lane] = (long long)__builtin_amdgcn_s_memrealtime();
                         }
                         all &= got[u];
                     }
-                    if (give_up && lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (give_up && !(exp_flags & 16) && lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     // watermark = the first ordinal of the block not delivered yet (ordinals run lane-minor): a step may need
                     // an early ordinal of this block to produce a later one of the same block
                     int wm = min(base + kPollBlock, n_ext);
@@ -431,11 +483,16 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                         if (open) wm = base + u * 64 + (int)__builtin_ctzll(open);
                     }
                     if (wm != wm_pub) { wm_pub = wm; if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)wm); }
+                    if (DBG) ++rounds;
                     if (!__ballot(!all)) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            if (DBG && lane == 0) a.dbg[(int64_t)t * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
+            if (DBG && lane == 0) {
+                a.dbg[(int64_t)t * 16 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
+                a.dbg[(int64_t)t * 16 + 8] = rounds;
+                a.dbg[(int64_t)t * 16 + 9] = (long long)__builtin_readcyclecounter() - c_poll;
+            }
         }
         __syncthreads();
     }
@@ -1183,16 +1240,24 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, p->xs, p->n + 1);
     BIS_HIP_CHECK(ctx, hipMemsetAsync(p->ticket, 0, sizeof(unsigned) * 4, ctx->stream));
     TiledArgs a{p->slot_row, p->step_desc, p->tile_slot0, p->tile_step0, p->tile_quad0, p->tile_ext0, p->quad_code, p->quad_val,
-                p->ext_src, p->xs, p->ticket, D, b, x, ctx->fault_dev, ctx->spmv_stop, p->n_tiles, nullptr};
+                p->ext_src, p->xs, p->ticket, D, b, x, ctx->fault_dev, ctx->spmv_stop, p->n_tiles, std::max(bis_opts().trsv_tile_exp, 0), nullptr, nullptr, nullptr, nullptr};
     static long long *dbg_buf = nullptr; // diagnostic (BIS_TRSV_TILE_DEBUG=file): per-tile stamps of the last sweep
     static int64_t dbg_cap = 0;
     const char *dbg_file = getenv("BIS_TRSV_TILE_DEBUG");
     if (dbg_file) {
-        if (dbg_cap < p->n_tiles) { hipFree(dbg_buf); hipMalloc(&dbg_buf, sizeof(long long) * 8 * (size_t)p->n_tiles); dbg_cap = p->n_tiles; }
-        hipMemsetAsync(dbg_buf, 0, sizeof(long long) * 8 * (size_t)p->n_tiles, ctx->stream);
+        // layout: 16 words per tile, then the publish stamp of every slot, then the delivery stamp of every external ordinal
+        const int64_t words = 16 * (int64_t)p->n_tiles + p->n + 1 + p->n_ext;
+        if (dbg_cap < words) { hipFree(dbg_buf); hipMalloc(&dbg_buf, sizeof(long long) * (size_t)words); dbg_cap = words; }
+        hipMemsetAsync(dbg_buf, 0, sizeof(long long) * (size_t)words, ctx->stream);
         a.dbg = dbg_buf;
+        static long long *dbg_step = nullptr;
+        if (!dbg_step) hipMalloc(&dbg_step, sizeof(long long) * 512);
+        hipMemsetAsync(dbg_step, 0, sizeof(long long) * 512, ctx->stream);
+        a.dbg_step = dbg_step;
+        a.dbg_pub = dbg_buf + 16 * (int64_t)p->n_tiles;
+        a.dbg_del = a.dbg_pub + p->n + 1;
     }
-    // LEAN: 19 KiB of LDS per workgroup, 8 workgroups per CU; WIDE: 38 KiB, 4 per CU (the occupancy query has the last word)
+    // resident workgroups per CU: what the occupancy query says (4 with today's register count, either budget)
     static int resident[2] = {0, 0};
     int &res = resident[p->lean ? 0 : 1];
     if (res == 0) {
@@ -1201,23 +1266,44 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trsv_tiled_kernel<CfgWide, false>, 256, 0);
         res = (oe == hipSuccess && nb > 0) ? std::min(nb, 8) : 1;
         (void)hipGetLastError();
+        if (getenv("BIS_TRSV_TILE_STATS")) fprintf(stderr, "tiled sptrsv: %d workgroups per CU resident (%s budget)\n", res, p->lean ? "LEAN" : "WIDE");
     }
-    // measured on the 7-point 256^3 grid (8^3 tiles): 3 / 4 / 5 / 7 workgroups per CU 0.88 / 0.84 / 0.85 / 0.95 ms
-    const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, res) : std::min(res, 4);
+    const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, res) : res;
     const int grid = (int)std::min<int64_t>(p->n_tiles, (int64_t)ctx->n_cus * per_cu);
+    const bool exp = a.exp_flags != 0;
     if (p->lean) {
-        if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, true, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        else if (exp) hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, false, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
     } else {
-        if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, true, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        else if (exp) hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, false, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
     }
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (dbg_file) {
-        std::vector<long long> h((size_t)p->n_tiles * 8);
+        // file: {tiles, slots, external ordinals}, the stamps, then the producing slot of every ordinal and the tiles' first ordinals
+        const int64_t words = 16 * (int64_t)p->n_tiles + p->n + 1 + p->n_ext;
+        std::vector<long long> h((size_t)words);
+        std::vector<int32_t> src((size_t)p->n_ext);
+        std::vector<int64_t> e0((size_t)p->n_tiles + 1), s0((size_t)p->n_tiles + 1);
         hipStreamSynchronize(ctx->stream);
         hipMemcpy(h.data(), dbg_buf, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-        if (FILE *f = fopen(dbg_file, "wb")) { fwrite(h.data(), sizeof(long long), h.size(), f); fclose(f); }
+        hipMemcpy(src.data(), p->ext_src, 4 * src.size(), hipMemcpyDeviceToHost);
+        hipMemcpy(e0.data(), p->tile_ext0, 8 * e0.size(), hipMemcpyDeviceToHost);
+        hipMemcpy(s0.data(), p->tile_slot0, 8 * s0.size(), hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(dbg_file, "wb")) {
+            const long long head[3] = {p->n_tiles, p->n + 1, p->n_ext};
+            fwrite(head, 8, 3, f);
+            fwrite(h.data(), sizeof(long long), h.size(), f);
+            fwrite(src.data(), 4, src.size(), f);
+            fwrite(e0.data(), 8, e0.size(), f);
+            fwrite(s0.data(), 8, s0.size(), f);
+            long long hs[512];
+            hipMemcpy(hs, a.dbg_step, sizeof(hs), hipMemcpyDeviceToHost);
+            fwrite(hs, 8, 512, f);
+            fclose(f);
+        }
     }
     return BIS_OK;
 }
