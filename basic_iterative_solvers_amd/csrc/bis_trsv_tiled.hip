@@ -158,7 +158,8 @@ struct TiledArgs {
     const int *stop; // a device schedule's stop flag (flags[1]): the sweep is a no-op once it is set
     int n_tiles;
     int exp_flags;  // option trsv_tile_exp (experiments, timing only -- results are wrong): 1 no x store, 2 no xs store, 4 no b / D loads,
-                    // 8 no entry loads, 16 external operands taken as delivered, 32 tiles dealt statically instead of by ticket
+                    // 8 no entry loads, 16 external operands taken as delivered, 32 tiles dealt statically instead of by ticket,
+                    // 64 stores of a step unmasked (results right), 128 nothing (the experiment build itself)
     long long *dbg; // DBG only, 16 words per tile (8, 9: the poller's rounds and the core cycles they took): start, end (s_memrealtime, 100 MHz), core cycles the compute wave waited for the
                     // loaders / for external operands, end of the quad loader / slot loader / poller, steps
     long long *dbg_step; // DBG only: core-cycle stamps inside the steps of the middle tile, 8 per step
@@ -240,18 +241,29 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     if (lane == 0) a.dbg_step[s * 8 + k] = c;
                 }
             };
+            // The loop is instantiated per row length (quads per row) where all steps of the tile agree on it -- the common
+            // case on a stencil -- and once for the general case: with the length a constant there is no branch over it and
+            // no padding-quad select in the step (the step is ~110 wave instructions at 8-10 cycles each; that count, not
+            // memory, is two thirds of the sweep: DESIGN.md section 4, second pass).
+            auto run_steps = [&](auto nqt) {
+            constexpr int NQT = decltype(nqt)::value; // 0: read per step
             for (int s = 0; s < n_steps; ++s) {
                 stamp(s, 0);
                 const int j = s & 63;
-                if (j == 0) {
-                    if (s > 0) d_cur = p_cur;
-                    p_cur = a.step_desc[sd0 + min(s + 64 + lane, n_steps - 1)];
+                if constexpr (NQT == 0) { // (the instances per row length have at most 64 steps: no second batch -- and a load nobody
+                                          // consumes would leave the register allocator free to reuse its destination, which costs
+                                          // an s_waitcnt vmcnt(0), i.e. the previous step's stores, in EVERY step: seen, 0.85 -> 1.09 ms)
+                    if (__builtin_expect(j == 0, 0)) {
+                        if (s > 0) d_cur = p_cur;
+                        p_cur = a.step_desc[sd0 + min(s + 64 + lane, n_steps - 1)];
+                    }
                 }
                 const int slot_b = __builtin_amdgcn_readlane(d_cur.x, j), wn = __builtin_amdgcn_readlane(d_cur.y, j);
                 const int quad_b = __builtin_amdgcn_readlane(d_cur.z, j), ext_end = __builtin_amdgcn_readlane(d_cur.w, j);
-                const int w = wn & 0xff, nq = wn >> 8;
+                const int w = wn & 0xff, nq = NQT ? NQT : (wn >> 8);
                 const int slot_e = slot_b + w, quad_e = quad_b + w * nq;
-                if (q_loaded < quad_e || slot_loaded < slot_e || ext_wm < ext_end) {
+                // (a lone wave pays for every taken branch with a refill of its instruction buffer: the step's usual path falls through)
+                if (__builtin_expect(q_loaded < quad_e || slot_loaded < slot_e || ext_wm < ext_end, 0)) {
                     // about to wait: tell the loaders and the poller how far their rings are free
                     if (lane == 0) {
                         lds_release(&ctl[C_Q_DONE], (unsigned)quad_b);
@@ -261,8 +273,8 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     unsigned spins = 0;
                     const long long t0 = DBG ? (long long)__builtin_readcyclecounter() : 0;
                     for (;;) {
-                        q_loaded = (int)lds_acquire(&ctl[C_Q_LOADED]);
-                        slot_loaded = (int)lds_acquire(&ctl[C_SLOT_LOADED]);
+                        q_loaded = __builtin_amdgcn_readfirstlane((int)lds_acquire(&ctl[C_Q_LOADED]));
+                        slot_loaded = __builtin_amdgcn_readfirstlane((int)lds_acquire(&ctl[C_SLOT_LOADED]));
                         if (q_loaded >= quad_e && slot_loaded >= slot_e) break;
                         if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     if (DBG) w_load += t1 - t0;
                     spins = 0; // (a budget of its own: the poller, which always moves the watermark on, gives up long before it runs out)
                     for (;;) {
-                        ext_wm = (int)lds_acquire(&ctl[C_EXT_WM]);
+                        ext_wm = __builtin_amdgcn_readfirstlane((int)lds_acquire(&ctl[C_EXT_WM]));
                         if (ext_wm >= ext_end) break;
                         if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -320,7 +332,8 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     }
                     qi += G * w;
                 };
-                if (nq == 1) group(std::integral_constant<int, 1>{}, 1);
+                if constexpr (NQT != 0) group(std::integral_constant<int, NQT>{}, NQT);
+                else if (nq == 1) group(std::integral_constant<int, 1>{}, 1);
                 else if (nq == 2) group(std::integral_constant<int, 2>{}, 2);
                 else for (int g = 0; g < nq; g += CFG::kGroup) group(std::integral_constant<int, CFG::kGroup>{}, nq - g);
                 if (DBG) { asm volatile("" :: "v"(acc)); stamp(s, 4); }
@@ -328,6 +341,11 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 unsigned long long out = (unsigned long long)__double_as_longlong(res);
                 if (DBG) { asm volatile("" :: "v"(out)); stamp(s, 5); }
                 if (res != res) out = kCanonNaN; // never publish the sentinel pattern
+                if (EXP && (exp_flags & 64)) { // (the stores unmasked: the lanes past w hold the last row's result again)
+                    __hip_atomic_store(&opnd[(slot_b + wl) & (kOwn - 1)], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    a.x[row] = __longlong_as_double((long long)out);
+                    __hip_atomic_store(&a.xs[slot0 + slot_b + wl], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else
                 if (lane < w) {
                     __hip_atomic_store(&opnd[(slot_b + lane) & (kOwn - 1)], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (!(exp_flags & 1)) a.x[row] = __longlong_as_double((long long)out);
@@ -335,13 +353,22 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     if (DBG) a.dbg_pub[slot0 + slot_b + lane] = (long long)__builtin_amdgcn_s_memrealtime();
                 }
                 stamp(s, 6);
-                if (lane == 0 && (s & 7) == 7) {
+                if (__builtin_expect((s & 7) == 7, 0) && lane == 0) {
                     lds_release(&ctl[C_Q_DONE], (unsigned)quad_b);
                     lds_release(&ctl[C_SLOT_DONE], (unsigned)slot_b);
                     lds_release(&ctl[C_EXT_SAFE], (unsigned)(ext_prev - kExtWindow));
                 }
                 ext_prev = ext_end;
             }
+            };
+            // (the first batch of descriptors tells; a tile of more than 64 steps takes the general loop)
+            const int nq_mine = lane < n_steps ? (d_cur.y >> 8) : -1;
+            const int nq_hi = -wave_min_int(-nq_mine), nq_lo = wave_min_int(lane < n_steps ? nq_mine : 0x7fffffff);
+            const int nq_all = __builtin_amdgcn_readfirstlane((n_steps <= 64 && nq_lo == nq_hi) ? nq_hi : 0);
+            if (nq_all == 1) run_steps(std::integral_constant<int, 1>{});
+            else if (nq_all == 2) run_steps(std::integral_constant<int, 2>{});
+            else if (nq_all == 4 && CFG::kGroup == 4) run_steps(std::integral_constant<int, 4>{});
+            else run_steps(std::integral_constant<int, 0>{});
             if (DBG && lane == 0) {
                 long long *d = a.dbg + (int64_t)t * 16;
                 d[0] = t_start; d[1] = (long long)__builtin_amdgcn_s_memrealtime(); d[2] = w_load; d[3] = w_ext;
