@@ -45,7 +45,7 @@ struct bis_trsv_tiled {
     int64_t *tile_step0 = nullptr;  // [n_tiles + 1] index into step_desc
     int64_t *tile_quad0 = nullptr;  // [n_tiles + 1]
     int64_t *tile_ext0 = nullptr;   // [n_tiles + 1]
-    int4 *quad_code = nullptr;      // [n_quads] 4 consecutive entries of one row: operand indices into the tile's LDS operand array
+    int4 *quad_code = nullptr;      // [n_quads] 4 consecutive entries of one row: BYTE offsets of their operands in the tile's LDS operand array
     double2 *quad_val = nullptr;    // [2 n_quads] their values (padding: value 0, operand = the zero slot)
     int32_t *ext_src = nullptr;     // [n_ext]  slot (global) whose published result the external ordinal stands for
     unsigned long long *xs = nullptr; // [n + 1] published results, by slot
@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256) void gather_entries_kernel(const double *__res
     }
 }
 
+struct __attribute__((aligned(16))) QuadRec { int4 c; double2 va, vb; };
+
 struct TiledArgs {
     const int32_t *slot_row;
     const int4 *step_desc;
@@ -181,8 +183,9 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
     // comes from): [0, kOwn) ring of the tile's own results by slot, [kOwn, kOwn + kExt) ring of the external operands
     // by ordinal, then the zero slot.
     __shared__ unsigned long long opnd[kOpnd];
-    __shared__ int4 ring_code[kRingQ + 1];       // (+ one permanent quad of padding entries, see the compute wave)
-    __shared__ double2 ring_val[2 * kRingQ + 2];
+    // quad ring: codes and values of a quad side by side (one index computation for the three reads; a 48-byte stride keeps
+    // 16-byte reads of consecutive lanes off each other's banks, which the 32-byte stride of a values-only array does not)
+    __shared__ QuadRec ring_q[kRingQ + 1];       // (+ one permanent quad of padding entries, see the compute wave)
     __shared__ int ring_row[kRingSlot];
     __shared__ double2 ring_bD[kRingSlot];
     __shared__ unsigned ctl[C_N];
@@ -190,9 +193,9 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
     if (a.stop && a.stop[1]) return;
     if (threadIdx.x == 0) {
         opnd[kZeroSlot] = 0ull;
-        ring_code[kRingQ] = make_int4(kZeroSlot, kZeroSlot, kZeroSlot, kZeroSlot);
-        ring_val[2 * kRingQ] = make_double2(0.0, 0.0);
-        ring_val[2 * kRingQ + 1] = make_double2(0.0, 0.0);
+        ring_q[kRingQ].c = make_int4(8 * kZeroSlot, 8 * kZeroSlot, 8 * kZeroSlot, 8 * kZeroSlot);
+        ring_q[kRingQ].va = make_double2(0.0, 0.0);
+        ring_q[kRingQ].vb = make_double2(0.0, 0.0);
     }
     unsigned dealt = blockIdx.x;
     for (;;) {
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             int q_loaded = 0, slot_loaded = 0, ext_wm = 0; // cached watermarks
             int ext_prev = 0;
             const long long c_first = DBG ? (long long)__builtin_readcyclecounter() : 0; // (descriptors are here: the steps begin)
+            auto opnd_at = [&](int byte_off) { return (const unsigned long long *)((const char *)opnd + byte_off); };
             auto stamp = [&](int s, int k) {
                 if (DBG && t == a.n_tiles / 2 && s < 64) {
                     const long long c = (long long)__builtin_readcyclecounter();
@@ -311,16 +315,17 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
 #pragma unroll
                     for (int u = 0; u < G; ++u) {
                         const int qq = u < g_left ? ((qi + u * w) & (kRingQ - 1)) : kRingQ;
-                        c[u] = ring_code[qq];
-                        va[u] = ring_val[2 * qq];
-                        vb[u] = ring_val[2 * qq + 1];
+                        c[u] = ring_q[qq].c;
+                        va[u] = ring_q[qq].va;
+                        vb[u] = ring_q[qq].vb;
                     }
                     if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(s, 2); }
                     unsigned long long xo[G][4];
 #pragma unroll
                     for (int u = 0; u < G; ++u) {
-                        xo[u][0] = lds_word(&opnd[c[u].x]); xo[u][1] = lds_word(&opnd[c[u].y]);
-                        xo[u][2] = lds_word(&opnd[c[u].z]); xo[u][3] = lds_word(&opnd[c[u].w]);
+                        // (the codes are byte offsets: an LDS read with the array's base in its offset field, no shift)
+                        xo[u][0] = lds_word(opnd_at(c[u].x)); xo[u][1] = lds_word(opnd_at(c[u].y));
+                        xo[u][2] = lds_word(opnd_at(c[u].z)); xo[u][3] = lds_word(opnd_at(c[u].w));
                     }
                     if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(s, 3); }
 #pragma unroll
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             };
             if (exp_flags & 8) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) { c_n[u] = make_int4(kZeroSlot, kZeroSlot, kZeroSlot, kZeroSlot); va_n[u] = vb_n[u] = make_double2(0.0, 0.0); }
+                for (int u = 0; u < U; ++u) { c_n[u] = make_int4(8 * kZeroSlot, 8 * kZeroSlot, 8 * kZeroSlot, 8 * kZeroSlot); va_n[u] = vb_n[u] = make_double2(0.0, 0.0); }
             }
             if (n_quads > 0 && !(exp_flags & 8)) issue(0, min(kQuadChunk, n_quads));
             for (int done = 0; done < n_quads;) {
@@ -412,9 +417,9 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                     const int i = u * 64 + lane;
                     if (i < chunk) {
                         const int r = (done + i) & (kRingQ - 1);
-                        ring_code[r] = c[u];
-                        ring_val[2 * r] = va[u];
-                        ring_val[2 * r + 1] = vb[u];
+                        ring_q[r].c = c[u];
+                        ring_q[r].va = va[u];
+                        ring_q[r].vb = vb[u];
                     }
                 }
                 done += chunk;
@@ -770,7 +775,7 @@ static bis_status trsv_tiled_build_host(bis_ctx *ctx, const bis_mat *T, bool bac
                                 code[q] = kOwn + (ext_ord[(size_t)gs] & (kExt - 1));
                             }
                         }
-                        quad_code.push_back(make_int4(code[0], code[1], code[2], code[3]));
+                        quad_code.push_back(make_int4(8 * code[0], 8 * code[1], 8 * code[2], 8 * code[3])); // byte offsets into the operand array
                     }
                 step_desc.push_back(make_int4(s, w | (nq << 8), quad_b, n_ext_tile));
                 s += w;
@@ -1038,7 +1043,7 @@ __global__ __launch_bounds__(64) void plan_steps_kernel(PlanArgs a) {
                         }
                     }
                     if (FILL) {
-                        a.quad_code[quad0 + quad_i] = make_int4(code[0], code[1], code[2], code[3]);
+                        a.quad_code[quad0 + quad_i] = make_int4(8 * code[0], 8 * code[1], 8 * code[2], 8 * code[3]); // byte offsets into the operand array
                         double2 *qv = (double2 *)(a.quad_val + 4 * (quad0 + quad_i));
                         qv[0] = make_double2(v[0], v[1]);
                         qv[1] = make_double2(v[2], v[3]);
