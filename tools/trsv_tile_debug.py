@@ -109,14 +109,14 @@ for lo, hi in ((0, 64), (64, 256), (256, 768), (768, 2048)):
     if m.any(): print(f"tiles started with {lo}..{hi} tiles in flight: {work[samp][m].sum() / steps[samp][m].sum():.0f} core cycles per step ({m.sum()} sampled)")
 # one tile in the middle of the sweep, in detail: when each of its steps published, and per block of 8 external ordinals
 # (first-need order) when their producers published them and when the poller delivered them (us relative to the tile's first result)
-t = n_t // 2
-sp = np.unique(pub[slot0[t]:slot0[t + 1]])
-print(f"tile {t}: {len(sp)} steps published at", np.round((sp - first_pub[t]) / f, 2).tolist())
-e_pub = (pub[src[ext0[t]:ext0[t + 1]]] - first_pub[t]) / f
-e_dlv = (dlv[ext0[t]:ext0[t + 1]] - first_pub[t]) / f
-print("ordinal: producer published / delivered (us rel. to the tile's first result)")
-for i in range(0, len(e_pub), 8):
-    print(f"  {i:4d}: " + "  ".join(f"{a:6.2f}/{b:6.2f}" for a, b in zip(e_pub[i:i + 8], e_dlv[i:i + 8])))
+for t in [int(v) for v in os.environ.get('TILES', str(n_t // 2)).split(',')]:
+  sp = np.unique(pub[slot0[t]:slot0[t + 1]])
+  print(f"tile {t}: {len(sp)} steps published at", np.round((sp - first_pub[t]) / f, 2).tolist())
+  e_pub = (pub[src[ext0[t]:ext0[t + 1]]] - first_pub[t]) / f
+  e_dlv = (dlv[ext0[t]:ext0[t + 1]] - first_pub[t]) / f
+  print("ordinal: producer published / delivered (us rel. to the tile's first result)")
+  for i in range(0, len(e_pub), 8):
+      print(f"  {i:4d}: " + "  ".join(f"{a:6.2f}/{b:6.2f}" for a, b in zip(e_pub[i:i + 8], e_dlv[i:i + 8])))
 
 # inside the steps of the middle tile (core cycles): loop top -> operands ready checked -> codes/values/row read -> operands read
 # -> fma chain done -> division done -> stores issued; and from the stores to the next loop top
