@@ -82,6 +82,7 @@ struct bis_options {
     int trsv_tiled = -1;    // natural-order sweeps: -1 = tiled sweep (bis_trsv_tiled.hip) where its device plan applies (grid hint), 1 = also with the host plan, 2 = host plan only, 0 = level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
+    int trsv_tile_backoff = -1; // tiled sweep: a poller's pause grows by 64 cycles per round that delivers nothing, up to this many (default 16: HPCG-256 2.35 -> 2.30 ms per sweep, HPCG-128 0.77 -> 0.74, the 7-point grid unchanged; 0: never)
     int trsv_tile_exp = -1;  // tiled sweep, timing experiments (bis_trsv_tiled.hip, TiledArgs::exp_flags); results are wrong with any bit set
     int trsv_tile_lean = -1; // rows of at most this many entries run the tiled sweep with the small LDS budget (more workgroups per CU; default 8)
     int trsv_tile_edge = -1; // grid-hinted matrices: tile extents in nodes, e (cubic) or ex | ey << 8 | ez << 16 (default by row length; 0 = interval tiles of the natural order)

@@ -159,6 +159,7 @@ struct TiledArgs {
     unsigned *fault;
     const int *stop; // a device schedule's stop flag (flags[1]): the sweep is a no-op once it is set
     int n_tiles;
+    int backoff;    // option trsv_tile_backoff
     int exp_flags;  // option trsv_tile_exp (experiments, timing only -- results are wrong): 1 no x store, 2 no xs store, 4 no b / D loads,
                     // 8 no entry loads, 16 external operands taken as delivered, 32 tiles dealt statically instead of by ticket,
                     // 64 stores of a step unmasked (results right), 128 nothing (the experiment build itself)
@@ -251,6 +252,10 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             // memory, is two thirds of the sweep: DESIGN.md section 4, second pass).
             auto run_steps = [&](auto nqt) {
             constexpr int NQT = decltype(nqt)::value; // 0: read per step
+            // lane j: what step j needs loaded / delivered (at most 64 steps in these instances; lanes past the last step repeat it)
+            [[maybe_unused]] const int my_w = d_cur.y & 0xff;
+            [[maybe_unused]] const int my_qe = d_cur.z + my_w * NQT, my_se = d_cur.x + my_w, my_xe = d_cur.w;
+            [[maybe_unused]] int ready_to = 0; // steps below it are covered by the cached watermarks
             for (int s = 0; s < n_steps; ++s) {
                 stamp(s, 0);
                 const int j = s & 63;
@@ -266,8 +271,11 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 const int quad_b = __builtin_amdgcn_readlane(d_cur.z, j), ext_end = __builtin_amdgcn_readlane(d_cur.w, j);
                 const int w = wn & 0xff, nq = NQT ? NQT : (wn >> 8);
                 const int slot_e = slot_b + w, quad_e = quad_b + w * nq;
-                // (a lone wave pays for every taken branch with a refill of its instruction buffer: the step's usual path falls through)
-                if (__builtin_expect(q_loaded < quad_e || slot_loaded < slot_e || ext_wm < ext_end, 0)) {
+                // (a lone wave pays for every taken branch with a refill of its instruction buffer: the step's usual path falls through.
+                // Where a lane holds each step's descriptor -- the instances per row length -- the three watermark tests are made for
+                // all steps at once when the watermarks are re-read, and the step itself compares its number with the first uncovered one)
+                const bool must_wait = (NQT && !(EXP && (exp_flags & 256))) ? s >= ready_to : (q_loaded < quad_e || slot_loaded < slot_e || ext_wm < ext_end);
+                if (__builtin_expect(must_wait, 0)) {
                     // about to wait: tell the loaders and the poller how far their rings are free
                     if (lane == 0) {
                         lds_release(&ctl[C_Q_DONE], (unsigned)quad_b);
@@ -293,6 +301,10 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (DBG) w_ext += (long long)__builtin_readcyclecounter() - t1;
+                    if constexpr (NQT != 0) {
+                        const unsigned long long uncovered = __ballot(my_qe > q_loaded || my_se > slot_loaded || my_xe > ext_wm);
+                        ready_to = max(s + 1, uncovered ? (int)__builtin_ctzll(uncovered) : 64);
+                    }
                 }
                 stamp(s, 1);
                 // lanes past the step's width take the last row's slots (loaded, in range); their results are masked at the store
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             // lane, all in flight together) at a time; the watermark (all ordinals below it delivered) moves when a
             // block is complete ----
             constexpr int U = kPollBlock / 64;
-            int wm_pub = 0;
+            int wm_pub = 0, idle = 0;
             long long rounds = 0;
             const long long c_poll = DBG ? (long long)__builtin_readcyclecounter() : 0;
             for (int base = 0; base < n_ext; base += kPollBlock) {
@@ -514,10 +526,15 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                         const unsigned long long open = __ballot(!got[u]);
                         if (open) wm = base + u * 64 + (int)__builtin_ctzll(open);
                     }
-                    if (wm != wm_pub) { wm_pub = wm; if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)wm); }
+                    const bool moved = wm != wm_pub;
+                    if (moved) { wm_pub = wm; if (lane == 0) lds_release(&ctl[C_EXT_WM], (unsigned)wm); }
                     if (DBG) ++rounds;
                     if (!__ballot(!all)) break;
                     __builtin_amdgcn_s_sleep(1);
+                    // a poller whose rounds deliver nothing backs off (up to a.backoff x 64 cycles between rounds): most resident tiles
+                    // are far ahead of the wavefront, and their polling is load in the L2 the active tiles' rounds queue behind
+                    idle = moved ? 0 : min(idle + 1, a.backoff);
+                    for (int k = 0; k < idle; ++k) __builtin_amdgcn_s_sleep(1);
                 }
             }
             if (DBG && lane == 0) {
@@ -1272,7 +1289,7 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, p->xs, p->n + 1);
     BIS_HIP_CHECK(ctx, hipMemsetAsync(p->ticket, 0, sizeof(unsigned) * 4, ctx->stream));
     TiledArgs a{p->slot_row, p->step_desc, p->tile_slot0, p->tile_step0, p->tile_quad0, p->tile_ext0, p->quad_code, p->quad_val,
-                p->ext_src, p->xs, p->ticket, D, b, x, ctx->fault_dev, ctx->spmv_stop, p->n_tiles, std::max(bis_opts().trsv_tile_exp, 0), nullptr, nullptr, nullptr, nullptr};
+                p->ext_src, p->xs, p->ticket, D, b, x, ctx->fault_dev, ctx->spmv_stop, p->n_tiles, bis_opts().trsv_tile_backoff >= 0 ? std::min(bis_opts().trsv_tile_backoff, 64) : 16, std::max(bis_opts().trsv_tile_exp, 0), nullptr, nullptr, nullptr, nullptr};
     static long long *dbg_buf = nullptr; // diagnostic (BIS_TRSV_TILE_DEBUG=file): per-tile stamps of the last sweep
     static int64_t dbg_cap = 0;
     const char *dbg_file = getenv("BIS_TRSV_TILE_DEBUG");
