@@ -72,3 +72,12 @@ def test_python_sources_compile():
     assert len(files) > 15
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_tiled_sweep_step_loops_do_not_wait_for_their_stores():
+    """Code generation guard (tools/check_tiled_isa.py): the compute wave of the tiled sweep must not have picked up an
+    `s_waitcnt vmcnt(0)` per step -- it did once, through an unused load, and cost 27 % of the sweep."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_tiled_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
