@@ -265,7 +265,6 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_TRSV_TILE_ROWS")) v.trsv_tile_rows = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_WGS")) v.trsv_tile_wgs = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_EDGE")) v.trsv_tile_edge = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_TILE_LEAN")) v.trsv_tile_lean = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_EXP")) v.trsv_tile_exp = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_BACKOFF")) v.trsv_tile_backoff = atoi(e);
         return v;
@@ -308,7 +307,6 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_tile_rows")) o.trsv_tile_rows = value;
     else if (!strcmp(name, "trsv_tile_wgs")) o.trsv_tile_wgs = value;
     else if (!strcmp(name, "trsv_tile_edge")) o.trsv_tile_edge = value;
-    else if (!strcmp(name, "trsv_tile_lean")) o.trsv_tile_lean = value;
     else if (!strcmp(name, "trsv_tile_exp")) o.trsv_tile_exp = value;
     else if (!strcmp(name, "trsv_tile_backoff")) o.trsv_tile_backoff = value;
     else if (!strcmp(name, "dist_host_plan")) o.dist_host_plan = value;

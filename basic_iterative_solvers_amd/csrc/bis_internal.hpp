@@ -84,7 +84,6 @@ struct bis_options {
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
     int trsv_tile_backoff = -1; // tiled sweep: a poller's pause grows by 64 cycles per round that delivers nothing, up to this many (default 16: HPCG-256 2.35 -> 2.30 ms per sweep, HPCG-128 0.77 -> 0.74, the 7-point grid unchanged; 0: never)
     int trsv_tile_exp = -1;  // tiled sweep, timing experiments (bis_trsv_tiled.hip, TiledArgs::exp_flags); results are wrong with any bit set
-    int trsv_tile_lean = -1; // rows of at most this many entries run the tiled sweep with the small LDS budget (more workgroups per CU; default 8)
     int trsv_tile_edge = -1; // grid-hinted matrices: tile extents in nodes, e (cubic) or ex | ey << 8 | ez << 16 (default by row length; 0 = interval tiles of the natural order)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)
     int spmv_sellwin = -1; // dictionary SpMV with the block's x window in LDS and sliced-ELL codes (bis_spmv_sell.hip): 0 off (-1: on where the matrix qualifies)

@@ -36,7 +36,6 @@
 struct bis_trsv_tiled {
     int64_t n = 0;
     int n_tiles = 0, max_rows = 0;
-    bool lean = false;         // LDS budget the plan was laid out for (TiledCfg)
     int64_t n_steps = 0, n_quads = 0, n_ext = 0;
     // device arrays.  "slot" = position of a row in (tile, local level, processing order) order.
     int32_t *slot_row = nullptr;    // [n]  slot -> row
@@ -64,11 +63,12 @@ namespace {
 
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload (same as bis_sptrsv.hip)
 constexpr unsigned long long kCanonNaN = 0x7FF8000000000000ull;
-// LDS budget of a workgroup, two instantiations: LEAN (19 KiB; rows of up to 8 entries, up to 16 on large matrices) and
-// WIDE (38 KiB; longer rows need room for a step's entries); lean_budget() below chooses.  Both run 4 workgroups per CU:
-// the kernel takes 118-132 VGPRs (forced to 64 it spills and is 2x slower; 86 with kGroup = 2 buys a fifth workgroup and
-// loses as much in the steps -- DESIGN.md section 4, second pass), so LEAN's smaller rings pay through shorter start-up,
-// not through residency.
+// LDS budget of a workgroup: 51 KiB (operand rings 16, quad ring 24.6, per-row rings 10), 3 workgroups per CU -- which is
+// also what the kernel's ~135 VGPRs allow.  The quad ring is what the size buys: the entry loader has one round of
+// global loads in flight at a time, so the ring's depth is how far it runs ahead of the compute wave.  Measured (sweeps
+// of HPCG-256 / the 7-point 256^3 grid, ms): a 128-quad ring with 4 workgroups per CU 2.31 / 0.81, 256 quads with 3 per CU
+// 2.17 / 0.69, 512 quads 2.14 / 0.66 -- and 1.75 with the 8x8x4 tiles the deeper ring makes affordable; 64 or 256 quads per
+// loader round instead of 128, 256 external ordinals per poll round instead of 128: no better.
 template <int OWN, int EXT, int WINDOW, int RINGQ, int RINGSLOT, int QCHUNK, int SCHUNK, int GROUP>
 struct TiledCfg {
     static constexpr int kGroup = GROUP;     // quads of a row the compute wave reads together (registers: 20 per quad)
@@ -83,16 +83,8 @@ struct TiledCfg {
     static constexpr int kQuadChunk = QCHUNK; // quads per loader round
     static constexpr int kSlotChunk = SCHUNK; // rows per loader round
 };
-using CfgLean = TiledCfg<512, 512, 128, 128, 256, 64, 128, 4>;
-using CfgWide = TiledCfg<1024, 1024, 256, 256, 512, 128, 256, 4>;
+using Cfg = TiledCfg<1024, 1024, 256, 512, 512, 128, 256, 4>;
 constexpr int kMaxB = 32768;      // rows per tile at most
-// Rows of at most 8 entries take the LEAN budget; rows of up to 16 too on large matrices, where the sweep is bound by the number
-// of tiles in flight (HPCG-256: 3.18 -> 2.69 ms per sweep) -- on small ones the shorter steps the smaller quad ring forces cost
-// more than the residency gains (HPCG-64 0.53 -> 0.70, HPCG-128 1.01 -> 1.09 ms).  Option trsv_tile_lean overrides the length.
-inline bool lean_budget(int max_len, int64_t n) {
-    if (bis_opts().trsv_tile_lean >= 0) return max_len <= bis_opts().trsv_tile_lean;
-    return max_len <= 8 || (max_len <= 16 && n >= ((int64_t)1 << 22));
-}
 constexpr unsigned kSpinLds = 1u << 26;  // polls of an LDS word before a wave gives up (several seconds: longer than the poller's budget below)
 constexpr unsigned kSpinMem = 1u << 20;  // polls of a memory word (about a second)
 
@@ -562,9 +554,7 @@ static bis_status trsv_tiled_build_host(bis_ctx *ctx, const bis_mat *T, bool bac
     if (st != BIS_OK) return st;
     int max_len = 0;
     for (int64_t r = 0; r < n; ++r) max_len = std::max<int>(max_len, (int)(rp[r + 1] - rp[r]));
-    const bool lean = lean_budget(max_len, n); // which LDS budget the sweep will run with (TiledCfg)
-    const int kOwn = lean ? CfgLean::kOwn : CfgWide::kOwn, kExt = lean ? CfgLean::kExt : CfgWide::kExt;
-    const int kExtWindow = lean ? CfgLean::kExtWindow : CfgWide::kExtWindow, kRingQ = lean ? CfgLean::kRingQ : CfgWide::kRingQ;
+    const int kOwn = Cfg::kOwn, kExt = Cfg::kExt, kExtWindow = Cfg::kExtWindow, kRingQ = Cfg::kRingQ;
     const int kZeroSlot = kOwn + kExt;
     if ((max_len + 3) / 4 > kRingQ / 2) return BIS_OK; // a single row must fit half the quad ring
     // The processing order: ord[pos] = row, any linear extension of the dependency order (every operand of a row sits
@@ -573,14 +563,14 @@ static bis_status trsv_tiled_build_host(bis_ctx *ctx, const bis_mat *T, bool bac
     std::vector<int32_t> ord((size_t)n), pos_v((size_t)n);
     std::vector<int64_t> tile_pos0;
     bool grid_tiles = false;
-    // tile extents in nodes: trsv_tile_edge = e (cubic) or ex | ey << 8 | ez << 16.  Defaults from tools/trsv_ab.py, forward /
-    // backward sweep in ms (level-scheduled kernels: 2.53 / 2.51, 2.21 / 2.37, 3.42 / 4.95):
-    //   7-point 256^3 (3 operands per row): 8x8x8 0.84 / 0.84; 6^3 1.14; 12x8x8 0.97; 16x8x8 1.05; 32x8x4 1.07; 16^3 2.5
-    //   27-point 128^3 (13):                 8x4x4 0.94 / 0.98; 16x4x2 1.03; 16x4x4 1.05; 32x4x4 1.14; 6^3 1.41; 8^3 2.24
-    //   FEM-like 80x80x81x3 (~35):           2x2x2 2.83 / 2.82; 4x2x2 3.27; 3^3 3.75; 8x2x2 4.9
-    // small tiles win: a hop costs the tile's extent in levels plus a memory round trip, and ~1800 resident tiles hide the
-    // start-up loads of the ones whose turn comes next
-    const int edge_default = max_len <= 8 ? (8 | 8 << 8 | 8 << 16) : max_len <= 16 ? (8 | 4 << 8 | 4 << 16) : (2 | 2 << 8 | 2 << 16);
+    // tile extents in nodes: trsv_tile_edge = e (cubic) or ex | ey << 8 | ez << 16.  Defaults from tools/trsv_ab.py with the
+    // 512-quad ring, forward / backward sweep in ms:
+    //   7-point 256^3 (3 operands per row): 8x8x8 0.65 / 0.65; 16x8x8 0.74; 8x16x8 0.79; 8x8x16 0.75; 16x16x8 1.13; 8x8x4 1.69
+    //   27-point 256^3 (13):                8x8x4 1.75 / 1.78; 8x4x4 2.14; 8x4x8 1.88; 16x8x4 1.92; 8x16x4 2.03; 8^3 2.12; 8x8x2 2.19
+    //   FEM-like 80x80x81x3 (~35):          2x2x2 2.28 / 2.28; 3^3 2.55
+    // a hop costs the tile's extent in levels plus a memory round trip; a tile costs its start-up (ticket, descriptors, first
+    // loader rounds: ~4 us); the deeper the quad ring, the larger the tile that still runs at the compute wave's pace
+    const int edge_default = max_len <= 8 ? (8 | 8 << 8 | 8 << 16) : max_len <= 16 ? (8 | 8 << 8 | 4 << 16) : (2 | 2 << 8 | 2 << 16);
     const int edge_opt = bis_opts().trsv_tile_edge >= 0 ? bis_opts().trsv_tile_edge : edge_default;
     const int ex = edge_opt < 256 ? edge_opt : (edge_opt & 255), ey = edge_opt < 256 ? edge_opt : ((edge_opt >> 8) & 255), ez = edge_opt < 256 ? edge_opt : ((edge_opt >> 16) & 255);
     const int edge = std::min(ex, std::min(ey, ez));
@@ -804,7 +794,7 @@ static bis_status trsv_tiled_build_host(bis_ctx *ctx, const bis_mat *T, bool bac
     tile_ext0[n_tiles] = (int64_t)ext_src.size();
     // upload
     bis_trsv_tiled *p = new bis_trsv_tiled;
-    p->n = n; p->n_tiles = (int)n_tiles; p->max_rows = tile_rows_max; p->lean = lean;
+    p->n = n; p->n_tiles = (int)n_tiles; p->max_rows = tile_rows_max;
     p->n_steps = (int64_t)step_desc.size();
     p->n_quads = (int64_t)quad_code.size();
     p->n_ext = (int64_t)ext_src.size();
@@ -1100,13 +1090,11 @@ static bis_status trsv_tiled_build_device(bis_ctx *ctx, const bis_mat *T, bool b
     if (n == 0 || T->nnz == 0 || T->nnz > (int64_t)600000000 || T->view || n >= INT32_MAX) return BIS_OK;
     if (!(T->grid[0] > 0 && T->grid[0] * T->grid[1] * T->grid[2] * T->grid[3] == n)) return BIS_OK;
     const int max_len = T->max_row_nnz;
-    const bool lean = lean_budget(max_len, n);
     PlanArgs a{};
-    a.kOwn = lean ? CfgLean::kOwn : CfgWide::kOwn; a.kExt = lean ? CfgLean::kExt : CfgWide::kExt;
-    a.kExtWindow = lean ? CfgLean::kExtWindow : CfgWide::kExtWindow; a.kRingQ = lean ? CfgLean::kRingQ : CfgWide::kRingQ;
+    a.kOwn = Cfg::kOwn; a.kExt = Cfg::kExt; a.kExtWindow = Cfg::kExtWindow; a.kRingQ = Cfg::kRingQ;
     a.kZeroSlot = a.kOwn + a.kExt;
     if ((max_len + 3) / 4 > a.kRingQ / 2) return BIS_OK;
-    const int edge_default = max_len <= 8 ? (8 | 8 << 8 | 8 << 16) : max_len <= 16 ? (8 | 4 << 8 | 4 << 16) : (2 | 2 << 8 | 2 << 16); // measured: trsv_tiled_build_host
+    const int edge_default = max_len <= 8 ? (8 | 8 << 8 | 8 << 16) : max_len <= 16 ? (8 | 8 << 8 | 4 << 16) : (2 | 2 << 8 | 2 << 16); // measured: trsv_tiled_build_host
     const int edge_opt = bis_opts().trsv_tile_edge >= 0 ? bis_opts().trsv_tile_edge : edge_default;
     PlanGeom g{};
     g.nx = T->grid[0]; g.ny = T->grid[1]; g.nz = T->grid[2]; g.dof = T->grid[3]; g.backward = backward ? 1 : 0;
@@ -1198,7 +1186,7 @@ static bis_status trsv_tiled_build_device(bis_ctx *ctx, const bis_mat *T, bool b
     const int64_t n_tiles = n_tiles32;
     bis_trsv_tiled *p = new bis_trsv_tiled;
     struct Guard { bis_trsv_tiled *p; ~Guard() { bis_trsv_tiled_destroy(p); } } guard{p};
-    p->n = n; p->n_tiles = (int)n_tiles; p->lean = lean;
+    p->n = n; p->n_tiles = (int)n_tiles;
     PLAN_CHECK(hipMalloc(&p->tile_slot0, 8 * (size_t)(n_tiles + 1)));
     PLAN_CHECK(hipMalloc(&p->tile_step0, 8 * (size_t)(n_tiles + 1)));
     PLAN_CHECK(hipMalloc(&p->tile_quad0, 8 * (size_t)(n_tiles + 1)));
@@ -1307,28 +1295,20 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
         a.dbg_del = a.dbg_pub + p->n + 1;
     }
     // resident workgroups per CU: what the occupancy query says (4 with today's register count, either budget)
-    static int resident[2] = {0, 0};
-    int &res = resident[p->lean ? 0 : 1];
+    static int res = 0;
+    const bool exp = a.exp_flags != 0;
     if (res == 0) {
         int nb = 0;
-        const hipError_t oe = p->lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trsv_tiled_kernel<CfgLean, false>, 256, 0)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trsv_tiled_kernel<CfgWide, false>, 256, 0);
+        const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trsv_tiled_kernel<Cfg, false>, 256, 0);
         res = (oe == hipSuccess && nb > 0) ? std::min(nb, 8) : 1;
         (void)hipGetLastError();
-        if (getenv("BIS_TRSV_TILE_STATS")) fprintf(stderr, "tiled sptrsv: %d workgroups per CU resident (%s budget)\n", res, p->lean ? "LEAN" : "WIDE");
+        if (getenv("BIS_TRSV_TILE_STATS")) fprintf(stderr, "tiled sptrsv: %d workgroups per CU resident\n", res);
     }
     const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, res) : res;
     const int grid = (int)std::min<int64_t>(p->n_tiles, (int64_t)ctx->n_cus * per_cu);
-    const bool exp = a.exp_flags != 0;
-    if (p->lean) {
-        if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, true, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-        else if (exp) hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, false, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((trsv_tiled_kernel<CfgLean, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    } else {
-        if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, true, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-        else if (exp) hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, false, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((trsv_tiled_kernel<CfgWide, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    }
+    if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<Cfg, true, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    else if (exp) hipLaunchKernelGGL((trsv_tiled_kernel<Cfg, false, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((trsv_tiled_kernel<Cfg, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (dbg_file) {
         // file: {tiles, slots, external ordinals}, the stamps, then the producing slot of every ordinal and the tiles' first ordinals

@@ -20,10 +20,9 @@ for c in cfgs:
     lib.bis_set_option(b"trsv_tile_rows", int(c.get("rows", -1)))
     lib.bis_set_option(b"trsv_tile_wgs", int(c.get("wgs", -1)))
     lib.bis_set_option(b"trsv_tile_edge", int(c.get("edge", -1)))
-    lib.bis_set_option(b"trsv_tile_lean", int(c.get("lean", -1)))
     lib.bis_set_option(b"trsv_tile_exp", int(c.get("exp", -1)))
     lib.bis_set_option(b"trsv_tile_backoff", int(c.get("backoff", -1)))
-    if "rows" in c or "fresh" in c or "edge" in c or "lean" in c:  # plans are cached per matrix: a new tile size needs fresh triangles
+    if "rows" in c or "fresh" in c or "edge" in c:  # plans are cached per matrix: a new tile size needs fresh triangles
         Ls, Us, D, Dinv = ctx.split_strict(A)
     t0 = time.perf_counter(); ctx.sptrsv(Ls, x, D, b); ctx.sync(); t_first = time.perf_counter() - t0
     lib.bis_set_option(b"trsv_one_xcd", int(c.get("one_xcd", -1)))
