@@ -475,6 +475,11 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
             int wm_pub = 0, idle = 0;
             long long rounds = 0;
             const long long c_poll = DBG ? (long long)__builtin_readcyclecounter() : 0;
+            // (the producing slots of the NEXT block are fetched while this block is polled: a block boundary otherwise costs a
+            // trip to memory during which nothing is looked for)
+            int src_next[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) src_next[u] = u * 64 + lane < n_ext ? a.ext_src[ext0 + u * 64 + lane] : 0;
             for (int base = 0; base < n_ext; base += kPollBlock) {
                 int src[U];
                 bool got[U];
@@ -482,7 +487,9 @@ __global__ __launch_bounds__(256) void trsv_tiled_kernel(const TiledArgs a) {
                 for (int u = 0; u < U; ++u) {
                     const int e = base + u * 64 + lane;
                     got[u] = e >= n_ext;
-                    src[u] = got[u] ? 0 : a.ext_src[ext0 + e];
+                    src[u] = src_next[u];
+                    const int e_next = e + kPollBlock;
+                    src_next[u] = e_next < n_ext ? a.ext_src[ext0 + e_next] : 0;
                 }
                 // the ring positions of this block are free once the ordinals kExt before them are dead
                 unsigned spins = 0;
