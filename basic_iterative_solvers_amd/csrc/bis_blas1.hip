@@ -308,6 +308,8 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_tile_wgs")) o.trsv_tile_wgs = value;
     else if (!strcmp(name, "trsv_tile_edge")) o.trsv_tile_edge = value;
     else if (!strcmp(name, "trsv_tile_exp")) o.trsv_tile_exp = value;
+    else if (!strcmp(name, "cg_nt_x")) o.cg_nt_x = value;
+    else if (!strcmp(name, "spmv_sellwin_nt")) o.spmv_sellwin_nt = value;
     else if (!strcmp(name, "trsv_tile_backoff")) o.trsv_tile_backoff = value;
     else if (!strcmp(name, "dist_host_plan")) o.dist_host_plan = value;
     else if (!strcmp(name, "trsv_inject_loss")) o.trsv_inject_loss = value;

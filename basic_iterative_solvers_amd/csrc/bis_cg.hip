@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void cg_finish_pap_kernel(const double *__rest
 
 // pass B: r -= alpha tmp; z = r/D (or r); (r,z), (r,r); the last workgroup reduces them and, on one
 // GPU, does the iteration's bookkeeping (DIST: the sums go through an all-reduce first, then cg_book_kernel).
+typedef double cg_v2d_t __attribute__((ext_vector_type(2)));
 template <bool JACOBI, bool DIST>
 __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, double *sc, int *flags,
                                                        const double *__restrict__ tmp,
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, double *sc, in
                                                        double *__restrict__ r,
                                                        double *__restrict__ z,
                                                        double *partials, size_t stride, unsigned *counter,
-                                                       double *hist, int hist_cap) {
+                                                       double *hist, int hist_cap, int nt_tmp) {
     __shared__ double lds[kT / 64];
     __shared__ bool last;
     if (flags[1]) return;
@@ -148,7 +149,11 @@ __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, double *sc, in
     double2 *r2 = reinterpret_cast<double2 *>(r);
     double2 *z2 = reinterpret_cast<double2 *>(z);
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n2; i += gs) {
-        const double2 tv = t2[i];
+        double2 tv;
+        if (nt_tmp) { // A p is dead after this pass (the next SpMV overwrites it): no need to keep its lines
+            const cg_v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const cg_v2d_t *>(t2 + i));
+            tv = make_double2(v.x, v.y);
+        } else tv = t2[i];
         double2 rv = r2[i], zv;
         rv.x = fma(-alpha, tv.x, rv.x);        // cg.hpp:31
         rv.y = fma(-alpha, tv.y, rv.y);
@@ -208,6 +213,7 @@ __global__ void cg_book_kernel(double *sc, int *flags, double *hist, int hist_ca
 // less per iteration than updating x in pass B); p = z + beta p (cg.hpp:52; None: z == r).
 // `it` = the iteration this launch belongs to: when the stop test fired in THIS iteration the x
 // update still runs (the reference updates x before it samples the residual), later launches are no-ops.
+template <bool NT>
 __global__ __launch_bounds__(kT) void cg_p_update_kernel(int64_t n, const double *__restrict__ sc,
                                                          const int *__restrict__ flags, int it,
                                                          const double *__restrict__ z,
@@ -221,12 +227,17 @@ __global__ __launch_bounds__(kT) void cg_p_update_kernel(int64_t n, const double
     double2 *x2 = reinterpret_cast<double2 *>(x);
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n2; i += gs) {
         const double2 zv = z2[i];
-        double2 pv = p2[i], xv = x2[i];
+        double2 pv = p2[i], xv;
+        if (NT) { // x is touched here and nowhere else in the iteration: keep it out of the caches p, r and A p live in
+            const cg_v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const cg_v2d_t *>(x2 + i));
+            xv = make_double2(v.x, v.y);
+        } else xv = x2[i];
         xv.x = fma(alpha, pv.x, xv.x);
         xv.y = fma(alpha, pv.y, xv.y);
         pv.x = fma(beta, pv.x, zv.x);
         pv.y = fma(beta, pv.y, zv.y);
-        x2[i] = xv;
+        if (NT) { cg_v2d_t v; v.x = xv.x; v.y = xv.y; __builtin_nontemporal_store(v, reinterpret_cast<cg_v2d_t *>(x2 + i)); }
+        else x2[i] = xv;
         p2[i] = pv;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -387,7 +398,7 @@ static bis_status cg_enqueue_iteration(bis_ctx *ctx, bis_cg *cg, int g, int it) 
 #define BIS_CG_UPDATE(J, D)                                                                                  \
     hipLaunchKernelGGL((cg_update_kernel<J, D>), dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags,    \
                        cg->tmp, cg->A_D, cg->r, cg->z, ctx->partials, (size_t)kMaxReduceBlocks,              \
-                       cg->counters + 1, cg->hist, cg->hist_cap)
+                       cg->counters + 1, cg->hist, cg->hist_cap, bis_opts().cg_nt_x != 0 && bis_opts().cg_nt_x != 2)
     if (cg->pc >= 0) BIS_CG_UPDATE(false, true); // r update and (r,r) only; z and (r,z) follow below
     else if (cg->dist) { if (cg->A_D) BIS_CG_UPDATE(true, true); else BIS_CG_UPDATE(false, true); }
     else { if (cg->A_D) BIS_CG_UPDATE(true, false); else BIS_CG_UPDATE(false, false); }
@@ -405,8 +416,8 @@ static bis_status cg_enqueue_iteration(bis_ctx *ctx, bis_cg *cg, int g, int it) 
         if (st != BIS_OK) return st;
         hipLaunchKernelGGL(cg_book_kernel, dim3(1), dim3(64), 0, ctx->stream, cg->sc, cg->flags, cg->hist, cg->hist_cap);
     }
-    hipLaunchKernelGGL(cg_p_update_kernel, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags, it,
-                       cg->z, cg->x, cg->p);
+    if (bis_opts().cg_nt_x != 0) hipLaunchKernelGGL(cg_p_update_kernel<true>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags, it, cg->z, cg->x, cg->p);
+    else hipLaunchKernelGGL(cg_p_update_kernel<false>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags, it, cg->z, cg->x, cg->p);
     return BIS_OK;
 }
 

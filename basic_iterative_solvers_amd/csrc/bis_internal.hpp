@@ -83,6 +83,8 @@ struct bis_options {
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
     int trsv_tile_backoff = -1; // tiled sweep: a poller's pause grows by 64 cycles per round that delivers nothing, up to this many (default 16: HPCG-256 2.35 -> 2.30 ms per sweep, HPCG-128 0.77 -> 0.74, the 7-point grid unchanged; 0: never)
+    int spmv_sellwin_nt = -1; // sliced-ELL SpMV: 0 = the code stream through the caches (default: non-temporal loads)
+    int cg_nt_x = -1;        // fused CG: 0 = x read and written through the caches in the p-update pass (default: non-temporal)
     int trsv_tile_exp = -1;  // tiled sweep, timing experiments (bis_trsv_tiled.hip, TiledArgs::exp_flags); results are wrong with any bit set
     int trsv_tile_edge = -1; // grid-hinted matrices: tile extents in nodes, e (cubic) or ex | ey << 8 | ez << 16 (default by row length; 0 = interval tiles of the natural order)
     int force_rp64 = -1;   // 1: matrices created afterwards get 64-bit row pointers whatever their size (tests of the HPCG-512 code path)

@@ -503,10 +503,11 @@ template <int MODE, bool DIAG, int FMT, int R, int NCH = 0>
 __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
     double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
-    const uint32_t *__restrict__ codes, const double *__restrict__ dict_g, const double *__restrict__ vdiag, int x_al16,
+    const uint32_t *__restrict__ codes, const double *__restrict__ dict_g, const double *__restrict__ vdiag, int x_flags,
     const int16_t *__restrict__ blk_base, int pair_stride, int n_pairs, int diag_pair, const int32_t *__restrict__ own_rank, long long *dbg) {
     using L = SwLayout<DIAG, FMT, R>;
     using Chunk = sw_chunk<FMT>;
+    const bool x_al16 = (x_flags & 1) != 0, nt_codes = (x_flags & 2) != 0; // x 16-byte aligned; the code stream read non-temporally
     if (stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int b = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
@@ -534,8 +535,13 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
         }
         const Chunk *cp = reinterpret_cast<const Chunk *>(codes) + (size_t)c0[r] * 64 + lane;
         const int last = max(nch[r] - 1, 0); // (the stream ends with one spare chunk: an empty last slice reads it)
+        if (FMT == 3 && nt_codes) { // (read once per product: kept out of the caches the vectors of the iteration live in)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) cd[r][q] = cp[(size_t)min(q, last) * 64];
+            for (int q = 0; q < 8; ++q) cd[r][q].a = __builtin_nontemporal_load(&cp[(size_t)min(q, last) * 64].a);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cd[r][q] = cp[(size_t)min(q, last) * 64];
+        }
         const int64_t row = (slice0 + r) * 64 + lane;
         wr[r] = 0.0;
         if (MODE == 1 && !own_rank && row < n_rows) wr[r] = w[row];
@@ -893,11 +899,11 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
 #define SW_L4(MODE, DIAG, FMT, RR)                                                                                     \
     hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, FMT, RR>), dim3(grid), dim3(256), (FMT == 3 ? win_off3 : (size_t)(SwLayout<DIAG, FMT, RR>::kWinOff)) + win, \
                        ctx->stream, x, y, A->n_rows, A->n_cols, sw->n_blocks, remap_arg, w, partials, stop, sw->hdr,   \
-                       sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16, sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own, dbg)
+                       sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16 | (bis_opts().spmv_sellwin_nt != 0 ? 2 : 0), sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own, dbg)
 #define SW_L4N(MODE, DIAG, RR, NN)                                                                                      \
     hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, 3, RR, NN>), dim3(grid), dim3(256), win_off3 + win,             \
                        ctx->stream, x, y, A->n_rows, A->n_cols, sw->n_blocks, remap_arg, w, partials, stop, sw->hdr,   \
-                       sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16, sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own, dbg)
+                       sw->slice_chunk0, sw->codes, sw->dict, A->vdiag, x_al16 | (bis_opts().spmv_sellwin_nt != 0 ? 2 : 0), sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own, dbg)
 #define SW_L3(MODE, DIAG, FMT) do {                                                                                    \
         if (FMT == 3 && sw->uniform_chunks == 7 && sw->R == 2) SW_L4N(MODE, DIAG, 2, 7);                               \
         else if (FMT == 3 && sw->uniform_chunks == 2 && sw->R == 2) SW_L4N(MODE, DIAG, 2, 2);                          \
