@@ -86,6 +86,15 @@ int main() {
     hipMalloc(&words, sizeof(unsigned long long) * 32 * n);
     hipMalloc(&turn, 4); hipMalloc(&xcc, 4 * n); hipMalloc(&ticks, 8 * n); hipMalloc(&lost, 4);
     long long *rounds; hipMalloc(&rounds, 16 * n);
+    // the same four modes with the exchanged words in fine-grained, then in uncached device memory (hipExtMallocWithFlags)
+    unsigned long long *words_plain = words, *words_fg = nullptr, *words_uc = nullptr;
+    if (hipExtMallocWithFlags((void **)&words_fg, sizeof(unsigned long long) * 32 * n, hipDeviceMallocFinegrained) != hipSuccess) words_fg = nullptr;
+    if (hipExtMallocWithFlags((void **)&words_uc, sizeof(unsigned long long) * 32 * n, hipDeviceMallocUncached) != hipSuccess) words_uc = nullptr;
+    (void)hipGetLastError();
+    for (int alloc = 0; alloc < 3; ++alloc) {
+    words = alloc == 0 ? words_plain : alloc == 1 ? words_fg : words_uc;
+    if (!words) { printf("allocation kind %d not available\n", alloc); continue; }
+    printf("--- words in %s memory\n", alloc == 0 ? "ordinary device" : alloc == 1 ? "fine-grained device" : "uncached device");
     for (int mode = 0; mode < 4; ++mode) {
         hipMemset(words, 0, sizeof(unsigned long long) * 32 * n);
         hipMemset(turn, 0, 4); hipMemset(ticks, 0, 8 * n); hipMemset(lost, 0, 4); hipMemset(rounds, 0, 16 * n);
@@ -111,6 +120,7 @@ int main() {
         printf("  one-way hand-off: same XCD %.3f us (%d partners), other XCD %.3f us (%d partners)\n", ns ? same / ns : 0.0, ns, no ? other / no : 0.0, no);
         printf("  consumer's poll round: same XCD %.0f core cycles (%.1f rounds per trip), other XCD %.0f (%.1f)\n", rs ? cs / rs : 0.0, ns ? rs / ns / kTrips : 0.0,
                ro ? co / ro : 0.0, no ? ro / no / kTrips : 0.0);
+    }
     }
     return 0;
 }
