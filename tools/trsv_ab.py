@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Time bis_sptrsv / bis_bsptrsv (natural order, sync-free kernel) for several option sets in one process.
-   python tools/trsv_ab.py hpcg 128 "one_xcd=0" "one_xcd=1" "one_xcd=2,grid=64" """
+"""Time bis_sptrsv / bis_bsptrsv (natural order) for several option sets in one process, and compare the results bit for bit.
+   python tools/trsv_ab.py hpcg 256 fresh=1 edge=264200 wgs=2 backoff=0          (tiled sweep: tile edges ex | ey << 8 | ez << 16,
+                                                                                 workgroups per CU, poller back-off; fresh=1: new plan)
+   python tools/trsv_ab.py hpcg 256 fresh=1 exp=128 exp=16                        (timing-only builds, TiledArgs::exp_flags: results wrong)
+   python tools/trsv_ab.py hpcg 128 tiled=0 "tiled=0,one_xcd=1" "tiled=0,grid=64" (level-scheduled kernels)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
