@@ -36,11 +36,42 @@ def ref_build_info():
         return {}
 
 
+def cpu_has_avx512():
+    """The prebuilt libraries are compiled for x86-64-v4 (oracle/Makefile MARCH): a host without AVX-512 would die
+    with SIGILL inside ctypes instead of failing a test."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return "avx512f" in line.split() and "avx512vl" in line.split()
+    except OSError:
+        pass
+    return False
+
+
+def host_march():
+    return "x86-64-v4" if cpu_has_avx512() else "x86-64-v3"
+
+
 def build(ref=True):
-    """Compile the oracle (and, when /root/reference exists, oracle/_ref)."""
-    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    """Compile the oracle (and, when /root/reference exists, oracle/_ref) for the ISA level this host has."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle", f"MARCH={host_march()}"])
+    with open(os.path.join(HERE, ".oracle_march"), "w") as f:
+        f.write(host_march())
     if ref:
-        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref", f"MARCH={host_march()}"])
+
+
+def _oracle_usable():
+    """libbisoracle.so exists and was built for an ISA level this CPU has (the file beside it says which; a library
+    of unknown level counts as x86-64-v4, the Makefile's default)."""
+    so = os.path.join(HERE, "libbisoracle.so")
+    if not os.path.exists(so):
+        return False
+    try:
+        built = open(os.path.join(HERE, ".oracle_march")).read().strip()
+    except OSError:
+        built = "x86-64-v4"
+    return built != "x86-64-v4" or cpu_has_avx512()
 
 
 class CRS:
@@ -95,9 +126,12 @@ def _crs_struct(A):
 
 class Oracle:
     def __init__(self, path=None):
-        path = path or os.path.join(HERE, "libbisoracle.so")
-        if not os.path.exists(path):
-            build(ref=False)
+        if path is None:
+            path = os.path.join(HERE, "libbisoracle.so")
+            if not _oracle_usable():  # missing, or built for AVX-512 on a host without it: rebuild (gcc is enough)
+                if os.path.exists(path):
+                    os.remove(path)
+                build(ref=False)
         self.lib = L = C.CDLL(path)
         L.orc_dot.restype = C.c_double
         L.orc_euclidean_vec_norm.restype = C.c_double
@@ -370,13 +404,25 @@ class Ref:
         path = os.path.join(HERE, "_ref", f"libbisref{variant}.so")
         if not os.path.exists(path):
             raise FileNotFoundError(path)
+        if not Ref.available(variant):
+            raise RuntimeError(f"{path} was built for {ref_build_info().get('flags')} and this CPU lacks AVX-512")
         self.lib = L = C.CDLL(path)
         L.ref_dot.restype = C.c_double
         L.ref_euclidean_vec_norm.restype = C.c_double
 
     @staticmethod
     def available(variant=""):
-        return os.path.exists(os.path.join(HERE, "_ref", f"libbisref{variant}.so"))
+        """The prebuilt reference can be loaded here: the file exists and this CPU has the ISA level it was
+        compiled for (build_info.json; it cannot be rebuilt where /root/reference is absent)."""
+        if not os.path.exists(os.path.join(HERE, "_ref", f"libbisref{variant}.so")):
+            return False
+        return "x86-64-v4" not in ref_build_info().get("flags", "x86-64-v4") or cpu_has_avx512()
+
+    def set_first_touch(self, on):
+        """1: the solver's matrix copy is made by the reference's own MatrixCRS::operator= (an OpenMP-parallel copy:
+        rows first touched by the threads that multiply them, sparse_matrix.hpp:92-128) instead of a memcpy by the
+        calling thread."""
+        self.lib.ref_set_first_touch(C.c_int(int(bool(on))))
 
     def _m(self, A):
         return (C.c_int(A.n_rows), C.c_int(A.nnz), A.rp32.ctypes, A.col.ctypes,

@@ -50,8 +50,22 @@ struct Borrowed {
     ~Borrowed() { m.row_ptr = nullptr; m.col = nullptr; m.val = nullptr; }
 };
 
+// 0: the matrix copy is written by the calling thread (memcpy: what a caller
+// that hands the reference host arrays gets).  1: through the reference's own
+// MatrixCRS::operator= (sparse_matrix.hpp:92-128), whose copy loop is an
+// `omp parallel for schedule(static)` over the rows -- the rows are first
+// touched by the threads that later multiply them (bench.py's
+// `cpu_baseline_first_touch` leg).
+int g_first_touch = 0;
+
 std::unique_ptr<MatrixCRS> own_copy(int n, int nnz, const int *rp,
                                     const int *col, const double *val) {
+    if (g_first_touch) {
+        Borrowed src(n, n, nnz, rp, col, val);
+        auto A = std::make_unique<MatrixCRS>();
+        *A = src.m;
+        return A;
+    }
     auto A = std::make_unique<MatrixCRS>(n, n, nnz);
     std::memcpy(A->row_ptr, rp, sizeof(int) * (n + 1));
     std::memcpy(A->col, col, sizeof(int) * nnz);
@@ -82,6 +96,8 @@ struct QuietStdout {
 } // namespace
 #include <fcntl.h>
 int QuietStdout::open_null() { return open("/dev/null", O_WRONLY); }
+
+REF_API void ref_set_first_touch(int on) { g_first_touch = on; }
 
 REF_API int ref_config(int *out6, double *outd5) {
     out6[0] = MAX_ITERS;

@@ -68,7 +68,7 @@ def test_bench_multi_gpu_path_rehearsal(world, precond, matrix):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--size", "48", "--steps", "6", "--warmup", "2",
-           "--precond", precond]
+           "--precond", precond, "--target-size", "0"]
     if matrix.startswith("anderson"):  # BASELINE config 3's runner: the conditioned twin and the config as named
         cmd += ["--matrix", "anderson", "--shift", "9" if matrix == "anderson" else "0"]
     env = dict(os.environ, OMP_NUM_THREADS="1", BIS_BENCH_REHEARSE="1")
@@ -88,3 +88,41 @@ def test_bench_multi_gpu_path_rehearsal(world, precond, matrix):
     for p in pr:  # every rank of a z-slab partition exchanges with its neighbours on every SpMV
         assert p["halo_entries"] > 0 and p["send_entries"] > 0 and p["exchanges"] == 6 and p["allreduces"] == 12
         assert p["neighbours"] >= 1 and p["interior_rows"] > 0 and p["rccl_ranks_seen"] == 0  # rehearsal: no RCCL
+    # the headline streams the CRS value array (north_star's CRS SpMV), priced on 12 nnz + 20 N ...
+    assert pr[0]["spmv_stream"]["val_bytes"] == 8 and j["roofline"]["algorithmic_bytes_per_launch"] == 12 * j["config"]["nnz"] + 20 * 48 ** 3
+    # ... and the library's default (compressed) format for these constant-coefficient / random-diagonal operators is a leg beside it
+    assert j["compressed_stream"]["per_rank"][0]["spmv_stream"]["val_bytes"] < 8 and j["compressed_stream"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_and_runs_the_north_star_leg():
+    """`python bench.py --gpus 3` invoked plainly (no torch.distributed.run around it, no WORLD_SIZE): bench.py starts its
+    ranks as a child process before anything touches the GPU and relays rank 0's ONE JSON line; the record carries the
+    strong-scaling leg on the north-star problem (`target_<size>`: HPCG 512^3 on a multi-GPU node; a rehearsal on one
+    GPU takes twice the main grid edge) with both stream formats and the per-rank SpMV / exchange / all-reduce times."""
+    import json
+    env = dict(os.environ, BIS_BENCH_REHEARSE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--size", "24", "--steps", "4", "--warmup", "1",
+                          "--target-steps", "3"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 3 and j["config"]["rows"] == 24 ** 3 and j["metric"].startswith("CG iterations/sec")
+    t = j["target_48"]
+    assert t["config"]["rows"] == 48 ** 3 and t["n_gpus"] == 3 and t["steps"] == 3 and t["value"] > 0
+    assert abs(t["residual_r0"] - t["residual_r0_closed_form"]) <= 1e-10 * t["residual_r0"]
+    assert t["per_rank"][0]["spmv_stream"]["val_bytes"] == 8 and t["compressed_stream"]["per_rank"][0]["spmv_stream"]["val_bytes"] < 8
+    for leg in (t, t["compressed_stream"]):
+        for p in leg["per_rank"]:
+            assert p["spmv_ms_per_iter"] > 0 and p["exchanges"] == 3 and p["allreduces"] == 6 and 0 < p["spmv_frac_of_peak"] < 1
+            assert "rccl_ranks_seen" in p and p["exchange_ms_per_iter"] >= 0 and p["allreduce_ms_per_iter"] >= 0
+
+
+def test_bench_refuses_a_world_that_does_not_match_gpus():
+    """Under a launcher, --gpus must equal WORLD_SIZE (the driver's contract); a mismatch is an error, not a silent 1-GPU run."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "--gpus 4" in (out.stderr + out.stdout)
