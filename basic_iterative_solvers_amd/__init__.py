@@ -134,6 +134,15 @@ class Context:
                                             C.c_uint64(seed), _i64(row0), _i64(row1), C.byref(h)))
         return Mat(self, h)
 
+    def gen_unstr(self, nx, ny=None, nz=None, keep=85, seed=1):
+        """fem: under a seeded random symmetric row permutation, ascending columns, no grid hint (config 5's unstructured input)."""
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        h = C.c_void_p()
+        self.check(self.lib.bis_mat_gen_unstr(self.h, _i64(nx), _i64(ny), _i64(nz), C.c_int(keep), C.c_uint64(seed),
+                                              None, C.byref(h)))
+        return Mat(self, h)
+
     def multicolour(self, A):
         """B = P A P^T grouped by colour; returns (B, perm[new]=old as numpy int32, n_colours)."""
         n = A.n_rows

@@ -21,6 +21,8 @@ ARCH = "gfx950"
 
 FLAGS = ["-std=c++17", "-O3", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+# e.g. BIS_EXTRA_HIPCC_FLAGS=-DBIS_TILED_EXP: the tiled sweep's timing-experiment / stamped builds (tools/trsv_ab.py, tools/trsv_tile_debug.py)
+FLAGS += os.environ.get("BIS_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _newer(src, dst):

@@ -243,8 +243,9 @@ bis_status bis_trsv_blocks_device(bis_ctx *ctx, const bis_mat *T, bool backward,
 // diagonal (or out of range) was found; the other outputs are then meaningless.
 bis_status bis_trsv_analyse_device(bis_ctx *ctx, const bis_mat *T, bool backward, int32_t *perm_dev,
                                    std::vector<int64_t> &level_ptr, int &n_levels, int64_t &max_width,
-                                   bool &triangular) {
+                                   bool &triangular, int **level_out) {
     const int64_t n = T->n_rows;
+    if (level_out) *level_out = nullptr;
     triangular = true;
     n_levels = 0;
     max_width = 0;
@@ -301,5 +302,6 @@ bis_status bis_trsv_analyse_device(bis_ctx *ctx, const bis_mat *T, bool backward
     BIS_AN_CHECK(hipStreamSynchronize(ctx->stream));
 #undef BIS_AN_CHECK
     for (int l = 0; l < n_levels; ++l) max_width = std::max<int64_t>(max_width, level_ptr[l + 1] - level_ptr[l]);
+    if (level_out) { *level_out = level; level = nullptr; } // (the sort read it, it did not change it)
     return cleanup(BIS_OK);
 }

@@ -262,10 +262,10 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_CG_GRAPH")) v.cg_graph = atoi(e);
         if (const char *e = getenv("BIS_FORCE_RP64")) v.force_rp64 = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILED")) v.trsv_tiled = atoi(e);
+        if (const char *e = getenv("BIS_TRSV_CHAIN")) v.trsv_chain = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_ROWS")) v.trsv_tile_rows = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_WGS")) v.trsv_tile_wgs = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_EDGE")) v.trsv_tile_edge = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_TILE_EXP")) v.trsv_tile_exp = atoi(e);
         if (const char *e = getenv("BIS_TRSV_TILE_BACKOFF")) v.trsv_tile_backoff = atoi(e);
         return v;
     }();
@@ -304,6 +304,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "cg_graph")) o.cg_graph = value;
     else if (!strcmp(name, "force_rp64")) o.force_rp64 = value;
     else if (!strcmp(name, "trsv_tiled")) o.trsv_tiled = value;
+    else if (!strcmp(name, "trsv_chain")) o.trsv_chain = value;
     else if (!strcmp(name, "trsv_tile_rows")) o.trsv_tile_rows = value;
     else if (!strcmp(name, "trsv_tile_wgs")) o.trsv_tile_wgs = value;
     else if (!strcmp(name, "trsv_tile_edge")) o.trsv_tile_edge = value;

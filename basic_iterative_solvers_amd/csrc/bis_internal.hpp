@@ -79,9 +79,11 @@ struct bis_options {
     int spmv_valdict = -1; // value dictionary (a matrix with <= 256 distinct values streams 1-byte value codes): 0 off, 1 consecutive form only, 2 lane-per-row form where it applies (-1: default)
     int dist_host_plan = -1; // 1: bis_dist_create plans the halo on the host from the downloaded structure (default: on the device)
     int grid_autodetect = -1; // bis_mat_create: recognise a stencil on a structured grid from the offsets of a few rows (0: off)
+    int trsv_chain = -1;    // natural-order sweeps of matrices without a grid: -1 = the chained sweep (bis_trsv_chain.hip) where its plan applies (chains of >= 3 rows on
+                            // average, fewer chains straddling a level than resident waves), 1 = also with shorter chains, 0 = level-scheduled kernels only
     int trsv_tiled = -1;    // natural-order sweeps: -1 = tiled sweep (bis_trsv_tiled.hip) where its device plan applies (grid hint), 1 = also with the host plan, 2 = host plan only, 0 = level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
-    int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default 2)
+    int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default: what fits, 3)
     int trsv_tile_backoff = -1; // tiled sweep: a poller's pause grows by 64 cycles per round that delivers nothing, up to this many (default 16: HPCG-256 2.35 -> 2.30 ms per sweep, HPCG-128 0.77 -> 0.74, the 7-point grid unchanged; 0: never)
     int spmv_sellwin_nt = -1; // sliced-ELL SpMV: 0 = the code stream through the caches (default: non-temporal loads)
     int cg_nt_x = -1;        // fused CG: 0 = x read and written through the caches in the p-update pass (default: non-temporal)
@@ -174,6 +176,9 @@ struct bis_mat {
     // the tiled natural-order sweep's plans (bis_trsv_tiled.hip), tried first: where they exist no level analysis is made
     struct bis_trsv_tiled *tiled_fwd = nullptr, *tiled_bwd = nullptr;
     bool tiled_tried_fwd = false, tiled_tried_bwd = false;
+    // the chained sweep's plans (bis_trsv_chain.hip), for matrices without a grid: built from the level analysis
+    struct bis_trsv_chain *chain_fwd = nullptr, *chain_bwd = nullptr;
+    bool chain_tried_fwd = false, chain_tried_bwd = false;
 };
 
 #define BIS_HIP_CHECK(ctx, call)                                               \
@@ -311,10 +316,17 @@ struct bis_trsv_tiled;
 bis_status bis_trsv_tiled_build(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_tiled **out);
 bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, const double *D, const double *b);
 void bis_trsv_tiled_destroy(bis_trsv_tiled *p);
-// device-side level analysis of a strictly triangular matrix (bis_analysis.hip)
+// device-side level analysis of a strictly triangular matrix (bis_analysis.hip); level_out (optional): the level of
+// every row, a device array the caller frees
 bis_status bis_trsv_analyse_device(bis_ctx *ctx, const bis_mat *T, bool backward, int32_t *perm_dev,
                                    std::vector<int64_t> &level_ptr, int &n_levels, int64_t &max_width,
-                                   bool &triangular);
+                                   bool &triangular, int **level_out = nullptr);
+// chained sweep (bis_trsv_chain.hip); *out stays null where it does not apply
+struct bis_trsv_chain;
+bis_status bis_trsv_chain_build(bis_ctx *ctx, const bis_mat *T, bool backward, const int *level_dev, int n_levels,
+                                bis_trsv_chain **out);
+bis_status bis_trsv_chain_solve(bis_ctx *ctx, const bis_mat *T, bis_trsv_chain *p, double *x, const double *D, const double *b);
+void bis_trsv_chain_destroy(bis_trsv_chain *p);
 // contiguous independent row blocks of a strictly triangular matrix, in processing order (bis_analysis.hip)
 bis_status bis_trsv_blocks_device(bis_ctx *ctx, const bis_mat *T, bool backward, int max_blocks,
                                   std::vector<int64_t> &bounds, int32_t *perm_dev, bool &triangular);

@@ -629,6 +629,8 @@ bis_status bis_mat_destroy(bis_ctx *ctx, bis_mat *A) {
     bis_trsv_plan_destroy(A->plan_bwd);
     bis_trsv_tiled_destroy(A->tiled_fwd);
     bis_trsv_tiled_destroy(A->tiled_bwd);
+    bis_trsv_chain_destroy(A->chain_fwd);
+    bis_trsv_chain_destroy(A->chain_bwd);
     if (!A->view) {
         hipFree(A->row_ptr);
         hipFree(A->col);
@@ -655,7 +657,7 @@ BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_tria
     BIS_REQUIRE(ctx, A && !A->view, "bis_mat_tune_placement: owning matrix required");
     // the streamed arrays are re-allocated: row views made earlier -- the triangular-solve plans cache some -- would
     // keep pointing at the freed ones
-    BIS_REQUIRE(ctx, !A->plan_fwd && !A->plan_bwd && !A->tiled_fwd && !A->tiled_bwd, "bis_mat_tune_placement: call it before the first triangular solve on this matrix");
+    BIS_REQUIRE(ctx, !A->plan_fwd && !A->plan_bwd && !A->tiled_fwd && !A->tiled_bwd && !A->chain_fwd && !A->chain_bwd, "bis_mat_tune_placement: call it before the first triangular solve on this matrix");
     if (first_ms) *first_ms = 0.0;
     if (best_ms) *best_ms = 0.0;
     if (A->nnz == 0 || A->n_rows == 0 || max_trials <= 0) return BIS_OK;

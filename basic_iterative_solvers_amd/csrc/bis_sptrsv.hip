@@ -43,6 +43,7 @@ struct bis_trsv_plan {
     double *xs = nullptr;    // device scratch, sentinel-filled before each solve
     bool no_pos = false;
     int32_t *pcol = nullptr; // device: position (in perm) of every column -- the scratch is kept in level order
+    int *level = nullptr;    // device: level of every row, kept until the chained sweep's plan has been tried (bis_trsv_chain.hip)
     unsigned *ticket = nullptr;
     int n_levels = 0;
     int64_t n = 0;
@@ -58,6 +59,7 @@ void bis_trsv_plan_destroy(bis_trsv_plan *p) {
     hipFree(p->perm);
     hipFree(p->xs);
     hipFree(p->pcol);
+    hipFree(p->level);
     hipFree(p->ticket);
     for (bis_mat *v : p->level_views) { // row views: only their block tables are theirs
         bis_mat_free_meta(v);
@@ -460,7 +462,8 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
     if (bis_opts().trsv_host_analysis <= 0) {
         // levels, level-sorted rows and the structure check on the device (bis_analysis.hip)
         bool triangular = true;
-        st = bis_trsv_analyse_device(ctx, T, backward, p->perm, p->level_ptr, p->n_levels, p->max_level_width, triangular);
+        st = bis_trsv_analyse_device(ctx, T, backward, p->perm, p->level_ptr, p->n_levels, p->max_level_width, triangular,
+                                     bis_opts().trsv_chain != 0 ? &p->level : nullptr);
         if (st == BIS_OK && !triangular) { ctx->err = not_tri; st = BIS_ERR_INVALID; }
         if (st != BIS_OK) { bis_trsv_plan_destroy(p); return st; }
         if (p->n_levels <= kFewLevels && n > 0) { // the contiguity test below reads the permutation
@@ -551,6 +554,25 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
         }
         BIS_HIP_CHECK(ctx, hipGetLastError());
         return BIS_OK;
+    }
+    // many narrow levels on a matrix without a grid: the chained sweep (bis_trsv_chain.hip) where its plan applies
+    if (bis_opts().trsv_chain != 0 && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_one_xcd <= 0) {
+        bis_mat *M = const_cast<bis_mat *>(T);
+        bis_trsv_chain *&cs = backward ? M->chain_bwd : M->chain_fwd;
+        bool &tried = backward ? M->chain_tried_bwd : M->chain_tried_fwd;
+        if (!tried) {
+            tried = true;
+            if (p->level) {
+                const bis_status cst = bis_trsv_chain_build(ctx, T, backward, p->level, p->n_levels, &cs);
+                hipFree(p->level);
+                p->level = nullptr;
+                if (cst != BIS_OK) return cst;
+            }
+        } else if (p->level) { // (a level plan rebuilt after the values changed: the chains depend on the pattern only)
+            hipFree(p->level);
+            p->level = nullptr;
+        }
+        if (cs) return bis_trsv_chain_solve(ctx, T, cs, x, D, b);
     }
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,

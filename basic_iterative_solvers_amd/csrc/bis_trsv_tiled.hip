@@ -1301,7 +1301,7 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
         a.dbg_pub = dbg_buf + 16 * (int64_t)p->n_tiles;
         a.dbg_del = a.dbg_pub + p->n + 1;
     }
-    // resident workgroups per CU: what the occupancy query says (4 with today's register count, either budget)
+    // resident workgroups per CU: what the occupancy query says (3: the 51 KiB of LDS and the ~135 VGPRs both allow exactly that)
     static int res = 0;
     const bool exp = a.exp_flags != 0;
     if (res == 0) {
@@ -1313,9 +1313,20 @@ bis_status bis_trsv_tiled_solve(bis_ctx *ctx, bis_trsv_tiled *p, double *x, cons
     }
     const int per_cu = bis_opts().trsv_tile_wgs > 0 ? std::min(bis_opts().trsv_tile_wgs, res) : res;
     const int grid = (int)std::min<int64_t>(p->n_tiles, (int64_t)ctx->n_cus * per_cu);
+    // The timing-experiment build of the kernel (exp_flags: results are WRONG with any bit but 64 set) and the stamped debug build
+    // exist only in a library compiled with -DBIS_TILED_EXP (tools/trsv_ab.py, tools/trsv_tile_debug.py: BIS_EXTRA_HIPCC_FLAGS);
+    // the product refuses the option instead of returning wrong numbers silently.
+#ifdef BIS_TILED_EXP
     if (dbg_file) hipLaunchKernelGGL((trsv_tiled_kernel<Cfg, true, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
     else if (exp) hipLaunchKernelGGL((trsv_tiled_kernel<Cfg, false, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((trsv_tiled_kernel<Cfg, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    else
+#else
+    if (dbg_file || exp) {
+        ctx->err = "tiled sptrsv: trsv_tile_exp / BIS_TRSV_TILE_DEBUG need a library built with -DBIS_TILED_EXP (timing experiments: wrong results by design)";
+        return BIS_ERR_INVALID;
+    }
+#endif
+    hipLaunchKernelGGL((trsv_tiled_kernel<Cfg, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (dbg_file) {
         // file: {tiles, slots, external ordinals}, the stamps, then the producing slot of every ordinal and the tiles' first ordinals

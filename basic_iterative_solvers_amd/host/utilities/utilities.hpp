@@ -3,7 +3,7 @@
 // and the same output layout.  Extra, MI355X-specific: the <matrix> argument
 // may be a generator string instead of a file (the reference does the same
 // with SCAMAC strings when built with -DUSE_SCAMAC, main.cpp:48-54):
-//     hpcg:N | hpcg:NX,NY,NZ | anderson:L[,shift=S][,W=w][,t=t][,seed=k] | fem:NX[,NY,NZ][,keep=K][,seed=k]
+//     hpcg:N | hpcg:NX,NY,NZ | anderson:L[,shift=S][,W=w][,t=t][,seed=k] | fem:NX[,NY,NZ][,keep=K][,seed=k] | unstr:NX[,NY,NZ][,keep=K][,seed=k]
 // and `-unfused` / `-dev K` select the kernel-by-kernel CG and the device;
 // `-perm mc` applies the multi-colour reordering of utilities/permute.hpp.
 #pragma once
@@ -209,7 +209,8 @@ inline bool make_generated_matrix(const std::string &spec, MatrixCRS *A) {
             else if (kv[0] == "seed") seed = strtoull(kv[1].c_str(), nullptr, 10);
         }
         bis::check(bis_mat_gen_anderson(bis::ctx(), L, t, W, shift, seed, 0, L * L * L, &m), "bis_mat_gen_anderson");
-    } else if (head[0] == "fem") { // fem:NX[,NY,NZ][,keep=K][,seed=S]  (3 unknowns per node)
+    } else if (head[0] == "fem" || head[0] == "unstr") { // fem:NX[,NY,NZ][,keep=K][,seed=S]  (3 unknowns per node); unstr: the same
+                                                          // under a seeded random row permutation, no grid (bis_mat_gen_unstr)
         long nx = atol(f[0].c_str()), ny = nx, nz = nx;
         int keep = 85;
         unsigned long long seed = 1;
@@ -223,7 +224,8 @@ inline bool make_generated_matrix(const std::string &spec, MatrixCRS *A) {
             if (kv[0] == "keep") keep = atoi(kv[1].c_str());
             else if (kv[0] == "seed") seed = strtoull(kv[1].c_str(), nullptr, 10);
         }
-        bis::check(bis_mat_gen_fem(bis::ctx(), nx, ny, nz, keep, seed, 0, 3 * nx * ny * nz, &m), "bis_mat_gen_fem");
+        if (head[0] == "unstr") bis::check(bis_mat_gen_unstr(bis::ctx(), nx, ny, nz, keep, seed, nullptr, &m), "bis_mat_gen_unstr");
+        else bis::check(bis_mat_gen_fem(bis::ctx(), nx, ny, nz, keep, seed, 0, 3 * nx * ny * nz, &m), "bis_mat_gen_fem");
     } else return false;
     A->adopt(m);
     return true;

@@ -218,6 +218,17 @@ BIS_API bis_status bis_mat_gen_fem(bis_ctx *ctx, int64_t nx, int64_t ny,
                                    int64_t nz, int keep_percent, uint64_t seed,
                                    int64_t row0, int64_t row1, bis_mat **out);
 
+/* Unstructured input (BASELINE config 5 "SuiteSparse unstructured", read in the
+ * reference through sparse_matrix.hpp:225-357; the .mtx is not fetchable): the
+ * FEM-like matrix above under a seeded random symmetric permutation of its rows,
+ * B = P A P^T, columns ascending inside a row, NO grid hint -- the triangular
+ * sweeps and ILU(0) of this matrix take the general (level-scheduled / chunked)
+ * kernels like any matrix read from a file.  perm[new] = old: stable ascending
+ * order of hash(seed ^ K3, old); written to perm_dev_out (n int32) if non-NULL. */
+BIS_API bis_status bis_mat_gen_unstr(bis_ctx *ctx, int64_t nx, int64_t ny,
+                                     int64_t nz, int keep_percent, uint64_t seed,
+                                     int32_t *perm_dev_out, bis_mat **out);
+
 /* Setup steps kept on the device:
  * split_LU (utilities/LU_factors.hpp:122-309): strict lower / strict upper
  * parts of A, row order preserved; and the diagonal extraction of

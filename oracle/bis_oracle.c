@@ -678,6 +678,69 @@ ORC_API int64_t orc_gen_fem(int64_t nx, int64_t ny, int64_t nz, int keep, uint64
     return row_ptr[n];
 }
 
+/* Unstructured input for config 5 (stands in for reading SuiteSparse Flan_1565.mtx through
+ * sparse_matrix.hpp:225-357; the file is not fetchable): the FEM-like matrix above under a
+ * seeded random symmetric permutation of its ROWS (not nodes), B = P A P^T, columns ascending
+ * inside a row -- no grid, no node blocks, no locality: what the reference's reader hands the
+ * solvers for a mesh whose numbering carries no structure.  perm[new] = old is the stable
+ * ascending order of the 64-bit keys hash(seed ^ K3, old) (ties, which a 64-bit hash makes
+ * practically impossible, keep the lower old index first).  The values are those of orc_gen_fem
+ * (the diagonal keeps the sum accumulated in A's column order). */
+#define FEM_K3 0x2545F4914F6CDD1Dull
+static inline uint64_t unstr_key(uint64_t seed, uint64_t i) {
+    uint64_t z = (seed ^ FEM_K3) * 0x9E3779B97F4A7C15ull + (i + 1) * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+typedef struct { uint64_t key; int64_t idx; } unstr_pair;
+static int unstr_cmp(const void *a, const void *b) {
+    const unstr_pair *x = (const unstr_pair *)a, *y = (const unstr_pair *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx < y->idx ? -1 : x->idx > y->idx;
+}
+ORC_API int orc_unstr_perm(int64_t n, uint64_t seed, int32_t *perm) {
+    unstr_pair *p = (unstr_pair *)malloc(sizeof(unstr_pair) * (size_t)(n > 0 ? n : 1));
+    if (!p) return 1;
+    for (int64_t i = 0; i < n; ++i) { p[i].key = unstr_key(seed, (uint64_t)i); p[i].idx = i; }
+    qsort(p, (size_t)n, sizeof(unstr_pair), unstr_cmp);
+    for (int64_t i = 0; i < n; ++i) perm[i] = (int32_t)p[i].idx;
+    free(p);
+    return 0;
+}
+typedef struct { int32_t c; double v; } unstr_ent;
+static int unstr_ent_cmp(const void *a, const void *b) {
+    const int32_t x = ((const unstr_ent *)a)->c, y = ((const unstr_ent *)b)->c;
+    return x < y ? -1 : x > y;
+}
+/* pass 1 (col == NULL): row_ptr[0..n], returns nnz; pass 2: col / val at those offsets.  perm = orc_unstr_perm. */
+ORC_API int64_t orc_gen_unstr(int64_t nx, int64_t ny, int64_t nz, int keep, uint64_t seed, const int32_t *perm,
+                              int64_t *row_ptr, int32_t *col, double *val) {
+    const int64_t n = 3 * nx * ny * nz;
+    if (!col) {
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < n; ++r) row_ptr[r + 1] = fem_row(nx, ny, nz, keep, seed, perm[r], NULL, NULL);
+        row_ptr[0] = 0;
+        for (int64_t r = 0; r < n; ++r) row_ptr[r + 1] += row_ptr[r];
+        return row_ptr[n];
+    }
+    int32_t *inv = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    if (!inv) return -1;
+    for (int64_t r = 0; r < n; ++r) inv[perm[r]] = (int32_t)r;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        int32_t c[81];
+        double v[81];
+        unstr_ent e[81];
+        const int64_t len = fem_row(nx, ny, nz, keep, seed, perm[r], c, v);
+        for (int64_t k = 0; k < len; ++k) { e[k].c = inv[c[k]]; e[k].v = v[k]; }
+        qsort(e, (size_t)len, sizeof(unstr_ent), unstr_ent_cmp); /* distinct columns: no ties */
+        for (int64_t k = 0; k < len; ++k) { col[row_ptr[r] + k] = e[k].c; val[row_ptr[r] + k] = e[k].v; }
+    }
+    free(inv);
+    return row_ptr[n];
+}
+
 /* Anderson-L: 7-point, periodic L^3 grid (L >= 3), off-diagonals -t,
  * diagonal W*(u-1/2)+shift with u = u01(seed,row); ascending columns; exactly
  * 7 nnz per row.  Generates rows [row0,row1), global columns. */

@@ -364,6 +364,27 @@ class Oracle:
         self.lib.orc_gen_fem(*args, rp.ctypes, col.ctypes, val.ctypes)
         return CRS(n, rp, col, val, n_cols=N)
 
+    def unstr_perm(self, n, seed=1):
+        perm = np.empty(n, dtype=np.int32)
+        if self.lib.orc_unstr_perm(C.c_int64(n), C.c_uint64(seed), perm.ctypes):
+            raise MemoryError
+        return perm
+
+    def gen_unstr(self, nx, ny=None, nz=None, keep=85, seed=1):
+        """The FEM-like matrix under a seeded random symmetric row permutation, ascending columns (orc_gen_unstr)."""
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        n = 3 * nx * ny * nz
+        perm = self.unstr_perm(n, seed)
+        rp = np.zeros(n + 1, dtype=np.int64)
+        self.lib.orc_gen_unstr.restype = C.c_int64
+        args = (C.c_int64(nx), C.c_int64(ny), C.c_int64(nz), C.c_int(keep), C.c_uint64(seed), perm.ctypes)
+        nnz = self.lib.orc_gen_unstr(*args, rp.ctypes, None, None)
+        col = np.empty(nnz, dtype=np.int32)
+        val = np.empty(nnz)
+        self.lib.orc_gen_unstr(*args, rp.ctypes, col.ctypes, val.ctypes)
+        return CRS(n, rp, col, val)
+
     def cg_run(self, A, iters, A_D=None, b_val=1.0, x0_val=0.1):
         """Plain CG loop for bench.py's cpu_baseline; returns (hist, seconds)."""
         hist = np.zeros(iters + 1)

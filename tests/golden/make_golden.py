@@ -193,8 +193,48 @@ def histories_mid(ref, orc):
     return out
 
 
+# Round 4: (i) raw (indefinite) Anderson, the operator of BASELINE configs 2-3 as named: the first 100 CG iterations
+# (SURVEY 8d parity gate item ii; cg.hpp:6-54 call order) -- CG need not converge there, the window is what is compared;
+# (ii) the unstructured config-5 input (`unstr:`: no grid, no node blocks) with the solver / preconditioner pairs of configs
+# 5 and 4.  histories_r4.json, data only.
+R4_RUNS = [
+    ("anderson16_raw", "anderson:16", lambda o: o.gen_anderson(16), [("cg", "none", dict(max_iters=100))]),
+    ("anderson32_raw", "anderson:32", lambda o: o.gen_anderson(32), [("cg", "none", dict(max_iters=100)),
+                                                                      ("cg", "j", dict(max_iters=100))]),
+    ("unstr_12x11x10", "unstr:12,11,10", lambda o: o.gen_unstr(12, 11, 10),
+     [("bi", "ilu0", dict(ilu_real=True)), ("gm", "gs", dict(restart_len=50)), ("cg", "sgs", {}), ("gs", "none", {})]),
+    ("unstr_20x20x20", "unstr:20,20,20", lambda o: o.gen_unstr(20, 20, 20),
+     [("bi", "ilu0", dict(ilu_real=True)), ("gm", "gs", dict(restart_len=50))]),
+]
+
+
+def histories_r4(ref, orc):
+    out = {}
+    for name, cli_arg, gen, runs in R4_RUNS:
+        A = gen(orc)
+        for solver, pc, kw in runs:
+            r = ref.solve(A, solver, pc, **kw)
+            o = orc.solve(A, solver, pc, **kw)
+            n = min(len(o["hist"]), len(r["hist"]))
+            d = np.abs(o["hist"][:n] - r["hist"][:n]) / r["hist"][0]
+            bad = np.nonzero(~(d <= 1e-9))[0]
+            key = f"{name}|{solver}|{pc}|" + ",".join(f"{k}={v}" for k, v in sorted(kw.items()))
+            out[key] = dict(cli=cli_arg, rows=A.n_rows, nnz=A.nnz, iters=r["iters"], converged=r["converged"],
+                            stopping=r["stopping"], final_true_residual=r["final_true_residual"],
+                            hist=[float(v) for v in r["hist"]], stable_len=int(bad[0]) if len(bad) else int(n),
+                            oracle_max_dev_over_r0=float(np.max(d)))
+            print(key, r["iters"], r["converged"], f"oracle dev {np.max(d):.2e} stable {out[key]['stable_len']}", flush=True)
+    with open(os.path.join(HERE, "histories_r4.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    return out
+
+
 def main():
     ref, orc = Ref(), Oracle()
+    if "--r4-only" in sys.argv:  # leaves the earlier fixtures as they are
+        h = histories_r4(ref, orc)
+        print(f"wrote {len(h)} round-4 histories")
+        return
     if "--mid-only" in sys.argv:  # leaves the small fixtures as they are
         h = histories_mid(ref, orc)
         print(f"wrote {len(h)} mid-size histories")
@@ -215,6 +255,7 @@ def main():
     print(f"wrote {len(h)} histories ({n_clean} complete) and "
           f"{len(mats) + 1} kernel fixture files")
     histories_mid(ref, orc)
+    histories_r4(ref, orc)
 
 
 if __name__ == "__main__":

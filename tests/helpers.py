@@ -41,6 +41,8 @@ def gen_from_cli_arg(orc, arg):
         return orc.gen_hpcg(*nums)
     if kind == "anderson":
         return orc.gen_anderson(nums[0], shift=kw.get("shift", 0.0))
+    if kind == "unstr":
+        return orc.gen_unstr(*nums)
     return orc.gen_fem(*nums)
 
 
@@ -89,7 +91,26 @@ HIST_TOL = {"cg": 1e-10, "j": 1e-10, "gs": 1e-10, "sgs": 1e-10, "gm": 1e-10,
             "bi": 1e-4}
 
 
-def check_history(r, e, solver, scale=1.0, stable_window=False):
+def load_histories_r4():
+    """Round-4 reference histories (tests/golden/make_golden.py --r4-only): the first 100 CG iterations on the raw
+    (indefinite) Anderson operator, and the unstructured config-5 input with the solver pairs of configs 5 and 4."""
+    with open(os.path.join(GOLDEN, "histories_r4.json")) as f:
+        return json.load(f)
+
+
+def permute_crs(A, perm):
+    """B = P A P^T for perm[new] = old, entries keeping their order inside a row (what bis_mat_permute builds)."""
+    perm = np.asarray(perm, dtype=np.int64)
+    n = A.n_rows
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    lens = np.diff(A.row_ptr)[perm]
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    src = np.repeat(A.row_ptr[:-1][perm] - rp[:-1], lens) + np.arange(rp[-1])
+    return CRS(n, rp, inv[A.col[src]].astype(np.int32), A.val[src])
+
+
+def check_history(r, e, solver, scale=1.0, stable_window=False, long_history=False):
     """stable_window: compare only the part of the reference history that is
     independent of rounding (golden `stable_len`: where the reference and the
     oracle -- same algorithm, different rounding -- still agree to 1e-9 r0).
@@ -128,7 +149,13 @@ def check_history(r, e, solver, scale=1.0, stable_window=False):
             # the reference (sequential sums of 10^5 terms in its dots) needs 104 iterations, the GPU (tree sums) 96,
             # the two histories 9e-13 r0 apart at most.  The histories themselves are held to `tol` over the common
             # window above, and the shorter run's last residual to `tol` of the longer one's at the same index below.
-            assert abs(len(h) - len(g)) <= max(2, len(g) // 10)
+            # (the wide allowance is for the mid-size inputs only -- `long_history` -- whose stopping iteration is the
+            # rounding noise described above; the small goldens hold at 2.  Either way the longer run's extra entries
+            # must already sit at the stopping threshold: within 10x of it.)
+            assert abs(len(h) - len(g)) <= (max(2, len(g) // 10) if long_history else 2)
             assert abs(h[n - 1] - g[n - 1]) <= tol * g[0]
+            longer = h if len(h) > len(g) else g
+            stop = e.get("stopping") or 1e-14 * g[0]
+            assert np.all(np.asarray(longer[n - 1:]) <= 10.0 * max(stop, 1e-14 * g[0]))
         else:
             assert r["converged"] == e["converged"]

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, check_history, load_histories, load_histories_mid, parse_hist_key
+from helpers import GOLDEN, check_history, load_histories, load_histories_mid, load_histories_r4, parse_hist_key
 
 pytestmark = pytest.mark.gpu
 
@@ -74,9 +74,64 @@ def test_cli_mid_size_history_vs_reference(key):
     r = run_cli(name, solver, pc, kw)
     # (r0 is a sum of 10^5 squares: the reference's sequential sum and the device's tree agree to 1.1e-13 on HPCG-48)
     assert abs(r["hist"][0] - e["hist"][0]) <= 1e-12 * e["hist"][0]
+    check_history(r, e, solver, stable_window=True, long_history=True)
+    if solver in ("cg", "j", "gs", "sgs") and len(r["hist"]) == len(e["hist"]):
+        assert r["iters"] == e["iters"]
+
+
+_H4 = load_histories_r4()
+
+
+@pytest.mark.parametrize("key", sorted(_H4))
+def test_cli_round4_histories_vs_reference(key):
+    """(i) BASELINE configs 2-3 as named run CG on the RAW Anderson operator (indefinite): the first 100 iterations of the
+    reference (cg.hpp:6-54; oracle/_ref at one thread with max_iters = 100) against the first 100 of the CLI's run --
+    SURVEY 8d's parity gate item (ii); the Jacobi-preconditioned run over the window in which the reference itself is
+    independent of rounding (`stable_len`).  (ii) Config 5's unstructured input (`unstr:`: the FEM-like matrix under a
+    random row permutation -- no grid hint, so the sweeps and ILU(0) take the general kernels) with the solver /
+    preconditioner pairs of configs 5 and 4, to convergence."""
+    e = _H4[key]
+    name, solver, pc, kw = parse_hist_key(key)
+    MATRIX_ARG[name] = e["cli"]
+    kw = dict(kw)
+    raw = kw.pop("max_iters", None)
+    r = run_cli(name, solver, pc, kw)
+    assert abs(r["hist"][0] - e["hist"][0]) <= 1e-12 * e["hist"][0]
+    if raw is not None:
+        n = min(len(e["hist"]), e.get("stable_len", len(e["hist"])))
+        assert len(r["hist"]) >= n
+        g, h = np.array(e["hist"][:n]), r["hist"][:n]
+        # (a window cut by `stable_len` is by definition the part on which differently rounded runs agree to 1e-9 r0)
+        assert np.max(np.abs(h - g)) / g[0] <= (1e-10 if n == len(e["hist"]) else 1e-9)
+        return
     check_history(r, e, solver, stable_window=True)
     if solver in ("cg", "j", "gs", "sgs") and len(r["hist"]) == len(e["hist"]):
         assert r["iters"] == e["iters"]
+
+
+@pytest.mark.parametrize("mode", ["rcm", "bfs"])
+@pytest.mark.parametrize("solver,pc", [("bi", "ilu0"), ("gm", "gs")])
+def test_cli_unstructured_input_reordered_vs_oracle_on_permuted_matrix(tmp_path, oracle, mode, solver, pc):
+    """The realistic pipeline for an unstructured mesh: `unstr:` (no locality at all) -> RCM / BFS on the device -> ILU(0)
+    / Gauss-Seidel sweeps in that order.  Parity target: the reference algorithm (oracle, real ILU(0)) on the same
+    permuted matrix P A P^T (the permutation is read back with -dump-perm)."""
+    from helpers import permute_crs
+    MATRIX_ARG["unstr_9x8x7"] = "unstr:9,8,7,seed=5"
+    permfile = str(tmp_path / "perm.txt")
+    kw = {"restart_len": 50} if solver == "gm" else {}
+    r = run_cli("unstr_9x8x7", solver, pc, kw, extra=["-perm", mode, "-dump-perm", permfile])
+    perm = np.loadtxt(permfile, dtype=np.int64)
+    A = oracle.gen_unstr(9, 8, 7, seed=5)
+    assert sorted(perm) == list(range(A.n_rows))
+    B = permute_crs(A, perm)
+    if mode == "rcm":  # the point of RCM on a matrix without locality: the bandwidth collapses
+        bw = lambda M: int(np.max(np.abs(M.col.astype(np.int64) - np.repeat(np.arange(M.n_rows), np.diff(M.row_ptr)))))
+        assert bw(B) < bw(A) // 3
+    o = oracle.solve(B, solver, pc, ilu_real=True, **kw)
+    e = dict(hist=[float(v) for v in o["hist"]], iters=o["iters"], converged=o["converged"])
+    check_history(r, e, solver)
+    if solver != "bi":
+        assert abs(r["iters"] - o["iters"]) <= 1
 
 
 @pytest.mark.parametrize("solver", ["j", "gs", "sgs"])

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import (GOLDEN, GOLDEN_MATS, check_history, crs_of, load_golden,
-                     load_histories, load_histories_mid, gen_from_cli_arg, parse_hist_key, relerr)
+                     load_histories, load_histories_mid, load_histories_r4, gen_from_cli_arg, parse_hist_key, relerr)
 from oracle.pyoracle import CRS
 
 KTOL = 1e-13  # kernel-level relative tolerance (SURVEY.md 8d parity gate)
@@ -134,6 +134,43 @@ def test_mid_size_residual_history_vs_golden(oracle, key):
     name, solver, pc, kw = parse_hist_key(key)
     r = oracle.solve(gen_from_cli_arg(oracle, e["cli"]), solver, pc, **kw)
     check_history(r, e, solver)
+
+
+_H4 = load_histories_r4()
+
+
+@pytest.mark.parametrize("key", sorted(_H4))
+def test_round4_residual_history_vs_golden(oracle, key):
+    """Raw (indefinite) Anderson: the first 100 CG iterations of the reference (SURVEY 8d parity gate item ii; with the
+    Jacobi preconditioner over the rounding-independent window); the unstructured config-5 input with -bi -p ilu0,
+    -gm -p gs, -cg -p sgs, -gs to convergence."""
+    e = _H4[key]
+    name, solver, pc, kw = parse_hist_key(key)
+    r = oracle.solve(gen_from_cli_arg(oracle, e["cli"]), solver, pc, **kw)
+    if "max_iters" in kw:
+        n = min(len(e["hist"]), e["stable_len"], len(r["hist"]))
+        assert n >= min(e["stable_len"], 101) and len(r["hist"]) == len(e["hist"])
+        g = np.array(e["hist"][:n])
+        # (a window cut by `stable_len` is by definition the part on which differently rounded runs agree to 1e-9 r0)
+        assert np.max(np.abs(np.asarray(r["hist"][:n]) - g)) / g[0] <= (1e-10 if n == len(e["hist"]) else 1e-9)
+        return
+    check_history(r, e, solver)
+
+
+def test_unstr_generator_is_the_permuted_fem_matrix(oracle):
+    """orc_gen_unstr = P A P^T of orc_gen_fem for perm = orc_unstr_perm, ascending columns, same values."""
+    from helpers import permute_crs
+    A = oracle.gen_fem(5, 4, 3, keep=70, seed=9)
+    B = oracle.gen_unstr(5, 4, 3, keep=70, seed=9)
+    perm = oracle.unstr_perm(A.n_rows, 9)
+    assert sorted(perm) == list(range(A.n_rows)) and not np.array_equal(perm, np.arange(A.n_rows))
+    P = permute_crs(A, perm)
+    assert np.array_equal(P.row_ptr, B.row_ptr)
+    for r in range(B.n_rows):
+        s, t = B.row_ptr[r], B.row_ptr[r + 1]
+        o = np.argsort(P.col[s:t], kind="stable")
+        assert np.array_equal(P.col[s:t][o], B.col[s:t]) and np.array_equal(P.val[s:t][o], B.val[s:t])
+        assert np.all(np.diff(B.col[s:t]) > 0)
 
 
 # ---- the reference's own unit-test vectors (tests/test_kernels.cpp,
