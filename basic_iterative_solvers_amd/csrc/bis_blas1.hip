@@ -305,6 +305,9 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "force_rp64")) o.force_rp64 = value;
     else if (!strcmp(name, "trsv_tiled")) o.trsv_tiled = value;
     else if (!strcmp(name, "trsv_chain")) o.trsv_chain = value;
+    else if (!strcmp(name, "trsv_chain_idle")) o.trsv_chain_idle = value;
+    else if (!strcmp(name, "trsv_chain_pause")) o.trsv_chain_pause = value;
+    else if (!strcmp(name, "trsv_chain_pairs")) o.trsv_chain_pairs = value;
     else if (!strcmp(name, "trsv_tile_rows")) o.trsv_tile_rows = value;
     else if (!strcmp(name, "trsv_tile_wgs")) o.trsv_tile_wgs = value;
     else if (!strcmp(name, "trsv_tile_edge")) o.trsv_tile_edge = value;

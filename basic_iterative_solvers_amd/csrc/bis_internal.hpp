@@ -81,6 +81,9 @@ struct bis_options {
     int grid_autodetect = -1; // bis_mat_create: recognise a stencil on a structured grid from the offsets of a few rows (0: off)
     int trsv_chain = -1;    // natural-order sweeps of matrices without a grid: -1 = the chained sweep (bis_trsv_chain.hip) where its plan applies (chains of >= 3 rows on
                             // average, fewer chains straddling a level than resident waves), 1 = also with shorter chains, 0 = level-scheduled kernels only
+    int trsv_chain_idle = -1;  // chained sweep: poll rounds without a delivery after which a feeder polls one word only (default 2)
+    int trsv_chain_pause = -1; // ... and pauses up to this many x 256 cycles between its looks (default 8)
+    int trsv_chain_pairs = -1; // wave pairs per ticket queue (default: all that are resident)
     int trsv_tiled = -1;    // natural-order sweeps: -1 = tiled sweep (bis_trsv_tiled.hip) where its device plan applies (grid hint), 1 = also with the host plan, 2 = host plan only, 0 = level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default: what fits, 3)

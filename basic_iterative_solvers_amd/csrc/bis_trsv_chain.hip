@@ -70,7 +70,7 @@ constexpr int kRowBatch = 32;         // rows whose b / D / length the feeder fe
 constexpr int kRowRing = 2 * kRowBatch;
 constexpr unsigned kSpinMem = 1u << 20;  // polls of a memory word before a wave gives up (about a second)
 constexpr unsigned kSpinLds = 1u << 26;  // polls of an LDS word (several seconds: longer than the feeder's own budget)
-constexpr int kBlocksPerCU = 7;       // 20.6 KiB of LDS per workgroup
+constexpr int kBlocksPerCU = 5;       // 20.8 KiB of LDS per workgroup; 5 per CU leaves each wave 102 VGPRs (at 7 the consumer spilled its chain registers: a trip to memory per row)
 
 enum { C_GEN = 0, C_ROW0, C_M, C_WM, C_DONE, C_ROWS_DONE, C_CHAIN_DONE, C_EXIT, C_N = 8 };
 
@@ -110,6 +110,8 @@ struct ChainArgs {
     const int *stop;
     int64_t n;
     int n_chains;
+    int idle_rounds; // poll rounds without a delivery after which a feeder polls one word only
+    int idle_cap;    // ... and pauses up to this many x 256 cycles between its looks
 };
 
 struct __attribute__((aligned(16))) Entry { double val; unsigned long long v; };
@@ -119,6 +121,7 @@ struct PairLds {
     double2 rbd[kRowRing];                // per row: b, D
     int rlen[kRowRing];                   // per row: number of entries
     unsigned long long res[kMaxChain];    // the chain's own results, by row & (kMaxChain - 1) (consumer only)
+    Entry zero[8];                        // a group of (0.0, 0.0) entries: what the consumer's fma chain reads behind a slot's end
     unsigned ctl[C_N];
 };
 
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
     PairLds &L = lds2[wv >> 1];
     const bool feeder = (wv & 1) == 0;
     if (threadIdx.x < 2 * C_N) lds2[threadIdx.x / C_N].ctl[threadIdx.x % C_N] = 0u;
+    if (threadIdx.x >= 64 && threadIdx.x < 80) { Entry &z = lds2[(threadIdx.x - 64) / 8].zero[threadIdx.x & 7]; z.val = 0.0; z.v = 0ull; }
     __syncthreads(); // (the only barrier: from here on the two pairs of the workgroup run on their own)
     const RP *rp = (const RP *)a.row_ptr;
     const unsigned pair_id = blockIdx.x * 2u + (unsigned)(wv >> 1);
@@ -242,30 +246,61 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                         }
                     }
 #pragma unroll
-                    for (int g = 0; g < kGroup; ++g) {
-                        if (g < n_seg) {
-                            Entry &E = L.ent[(slots_pub + (unsigned)g) & (kSlots - 1)][lane];
-                            E.val = lane < sg[g].cnt ? R[g].av : 0.0;
-                            // in order: a slot is published when all its operands are there (an operand of row j can only depend on rows
-                            // of this chain before j, whose slots are out already: waiting here cannot wait for the consumer's own future)
-                            unsigned spins = 0;
-                            unsigned long long vg = v[g];
-                            for (;;) {
-                                const bool pend = ext[g] && vg == kSentinel;
-                                if (!__ballot(pend)) break;
-                                ++spins;
-                                if (!aborted && (spins & 255u) == 0u) aborted = __builtin_amdgcn_readfirstlane((int)fault_raised(a.fault)) != 0;
-                                if (aborted || spins > kSpinMem) { // bounded: the row gets NaN, the context's fault word is raised
-                                    aborted = true;
-                                    if (lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                    if (pend) vg = kCanonNaN;
-                                    break;
-                                }
-                                if (pend) vg = __hip_atomic_load(&a.xs[R[g].c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __builtin_amdgcn_s_sleep(1);
+                    for (int g = 0; g < kGroup; ++g) // values first: the operands follow as they arrive
+                        if (g < n_seg) L.ent[(slots_pub + (unsigned)g) & (kSlots - 1)][lane].val = lane < sg[g].cnt ? R[g].av : 0.0;
+                    // Slots are published IN ORDER, each when all its operands are there (an operand of row j can only depend on rows of
+                    // this chain before j, whose slots are out already: waiting here never waits for the consumer's own future).  All
+                    // pending operands of the group are polled together, so operands that neighbouring chains produce row by row are
+                    // picked up a group per round trip, not a row per round trip.  A feeder whose rounds deliver nothing -- a chain taken
+                    // long before its turn: most of the resident pairs at any time -- falls back to ONE lane polling ONE word (the operand
+                    // produced last: the largest column of a forward, the smallest of a backward sweep) with a growing pause: thousands
+                    // of idle feeders re-reading all their pending words were most of the load on the L2 the active chains' hand-offs
+                    // queue behind.
+                    int pub = 0, idle = 0;
+                    bool delivered = false;
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool progressed = false;
+#pragma unroll
+                        for (int g = 0; g < kGroup; ++g) {
+                            if (g == pub && g < n_seg && !__ballot(ext[g] && v[g] == kSentinel)) {
+                                L.ent[(slots_pub + (unsigned)g) & (kSlots - 1)][lane].v = v[g];
+                                if (lane == 0) lds_release(&L.ctl[C_WM], slots_pub + (unsigned)g + 1u);
+                                ++pub;
+                                progressed = true;
                             }
-                            E.v = vg;
-                            if (lane == 0) lds_release(&L.ctl[C_WM], slots_pub + (unsigned)g + 1u);
+                        }
+                        if (pub >= n_seg) break;
+                        idle = (progressed || delivered) ? 0 : idle + 1; // (a delivery that does not complete a slot yet still says the wavefront is here)
+                        delivered = false;
+                        ++spins;
+                        if (!aborted && (spins & 255u) == 0u) aborted = __builtin_amdgcn_readfirstlane((int)fault_raised(a.fault)) != 0;
+                        if (aborted || spins > kSpinMem) { // bounded: the rows get NaN, the context's fault word is raised
+                            aborted = true;
+                            if (lane == 0) __hip_atomic_fetch_or(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+                            for (int g = 0; g < kGroup; ++g) if (ext[g] && v[g] == kSentinel) v[g] = kCanonNaN;
+                            continue;
+                        }
+                        if (idle < a.idle_rounds) {
+#pragma unroll
+                            for (int g = 0; g < kGroup; ++g)
+                                if (g >= pub && g < n_seg && ext[g] && v[g] == kSentinel)
+                                    v[g] = __hip_atomic_load(&a.xs[R[g].c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __builtin_amdgcn_s_sleep(1);
+                            // (deliveries show as published slots in the next round)
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < kGroup; ++g) {
+                                if (g == pub) {
+                                    const unsigned long long pend = __ballot(ext[g] && v[g] == kSentinel);
+                                    const int sel = BACKWARD ? (int)__builtin_ctzll(pend) : 63 - (int)__builtin_clzll(pend);
+                                    if (lane == sel) v[g] = __hip_atomic_load(&a.xs[R[g].c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    delivered = __ballot(lane == sel && v[g] != kSentinel) != 0ull;
+                                }
+                            }
+                            const int pause = min(idle - a.idle_rounds + 1, a.idle_cap);
+                            for (int i = 0; i < pause; ++i) __builtin_amdgcn_s_sleep(4);
                         }
                     }
                     slots_pub += (unsigned)n_seg;
@@ -320,56 +355,117 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                     __builtin_amdgcn_s_sleep(1);
                 }
             };
+            // (the next row's length, b / D and first entries are read while this row is divided and published: used if they were there)
+            bool have_n = false;
+            int len_n = 0;
+            double2 bd_n = make_double2(0.0, 1.0);
+            Entry E_n;
+            E_n.val = 0.0; E_n.v = 0ull;
             for (int j = 0; j < m; ++j) {
                 const int r = BACKWARD ? row0 - j : row0 + j;
-                wait_slot(slot + 1u); // (the row's b / D / length were written before its first slot was published)
-                const int len = __builtin_amdgcn_readfirstlane(L.rlen[j & (kRowRing - 1)]);
-                const double2 bd = L.rbd[j & (kRowRing - 1)];
+                // the row's length, b / D and this lane's entry of its first slot are read TOGETHER with the watermark that says whether
+                // they are there (the LDS runs a wave's reads in order: a watermark that covers the slot was read before data that is
+                // then valid) -- one LDS round trip per row instead of three
+                int len = len_n;
+                double2 bd = bd_n;
+                Entry E = E_n;
+                if (!have_n) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        wm = lds_acquire(&L.ctl[C_WM]);
+                        len = L.rlen[j & (kRowRing - 1)];
+                        bd = L.rbd[j & (kRowRing - 1)];
+                        E = L.ent[slot & (kSlots - 1)][lane];
+                        asm volatile("" ::: "memory");
+                        wm = (unsigned)__builtin_amdgcn_readfirstlane((int)wm);
+                        if ((int)(wm - (slot + 1u)) >= 0) break;
+                        if (++spins > kSpinLds) { if (lane == 0) __hip_atomic_fetch_or(a.fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                len = __builtin_amdgcn_readfirstlane(len);
                 double acc = 0.0;
                 int done = 0;
                 do { // a slot per 64 entries (at least one per row)
-                    wait_slot(slot + 1u);
-                    const Entry E = L.ent[slot & (kSlots - 1)][lane];
+                    Entry (&S)[64] = L.ent[slot & (kSlots - 1)];
+                    if (done > 0) { wait_slot(slot + 1u); E = S[lane]; }
                     const int cnt = min(64, len - done);
-                    unsigned long long v = E.v;
-                    if ((unsigned)(v >> 32) == kInternalTag) { // an operand this chain produced: the last three from registers, older ones from the ring
-                        const int dist = (int)(unsigned)v;
+                    // operands this chain produced itself (tagged by the feeder): the last three from registers, older ones from the ring --
+                    // resolved by the lanes that hold them and written back into the slot
+                    if ((unsigned)(E.v >> 32) == kInternalTag) {
+                        const int dist = (int)(unsigned)E.v;
                         const int orow = BACKWARD ? r + dist : r - dist;
-                        const unsigned long long w = __hip_atomic_load(&L.res[orow & (kMaxChain - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        v = dist == 1 ? p1 : dist == 2 ? p2 : dist == 3 ? p3 : w;
+                        const unsigned long long w = dist == 1 ? p1 : dist == 2 ? p2 : dist == 3 ? p3
+                                                     : __hip_atomic_load(&L.res[orow & (kMaxChain - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&S[lane].v, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    const double xv = __longlong_as_double((long long)v);
-                    // the chain acc_i = fma(a_i, x_i, acc_{i-1}) runs ACROSS the lanes (DPP wave_shr:1; lane 0 takes the carry of the previous
-                    // segment): entry i of the row is final in lane i after step i -- the reference's CRS-order fma chain exactly
-                    double lacc = 0.0;
-                    for (int i = 0; i < cnt; ++i) {
-                        const unsigned long long cur = (unsigned long long)__double_as_longlong(lacc);
-                        const unsigned long long seed = (unsigned long long)__double_as_longlong(acc);
-                        const unsigned tlo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)seed, (int)(unsigned)cur, 0x138, 0xf, 0xf, false);
-                        const unsigned thi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(seed >> 32), (int)(unsigned)(cur >> 32), 0x138, 0xf, 0xf, false);
-                        const double left = __longlong_as_double((long long)(((unsigned long long)thi << 32) | tlo));
-                        lacc = fma(E.val, xv, left);
-                    }
-                    if (cnt > 0) {
-                        const unsigned long long lb = (unsigned long long)__double_as_longlong(lacc);
-                        const unsigned long long fin = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(lb >> 32), cnt - 1) << 32) |
-                                                       (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)lb, cnt - 1);
-                        acc = __longlong_as_double((long long)fin);
+                    asm volatile("" ::: "memory");
+                    // acc = fma(a_i, x_i, acc) in CRS order -- the reference's chain exactly -- by ONE lane, reading entry after entry from the
+                    // slot (eight entries in flight ahead of the eight being summed; a one-lane LDS read moves 16 bytes, not a kilobyte: with
+                    // every lane reading the same entry the chain was bound by LDS bandwidth, 12.5 ns per entry; run across the lanes with
+                    // DPP moves -- each lane adding its entry to its left neighbour's sum -- it measured 32 ns per entry: tools/chain_probe.py).
+                    // The slot is padded with (0.0, 0.0) entries: fma(0, 0, acc) leaves acc as it is (acc is never -0.0: it starts at +0.0
+                    // and an exact cancellation rounds to +0.0), so the count is rounded up to the group and no step is predicated.
+                    if (lane == 0) {
+                        const int groups = (cnt + 7) >> 3;
+                        // (relaxed ATOMIC reads: an ordinary read whose value is only used if the loop goes on is sunk behind the loop's exit
+                        // test by the compiler, i.e. issued when it is needed instead of a group ahead.  Two register sets, A and B, by
+                        // unrolling: no moves.  A group past the row's entries is zeros -- the slot's padding, or the pair's zero group behind
+                        // the slot's end -- and adds nothing.)
+                        double aa[8], ax[8], ba[8], bx[8];
+                        const Entry *Z = L.zero;
+                        auto rdg = [&](int g, double (&va)[8], double (&vx)[8]) {
+                            const Entry *base = g < 8 ? &S[g * 8] : Z;
+                            // (one 16-byte LDS read per entry; volatile so that it stays where it is written, in the LDS address space so
+                            // that it stays an LDS read)
+                            typedef double v2d_lds __attribute__((ext_vector_type(2)));
+                            const volatile __attribute__((address_space(3))) v2d_lds *q = (const volatile __attribute__((address_space(3))) v2d_lds *)base;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const v2d_lds e = q[u];
+                                va[u] = e.x;
+                                vx[u] = e.y;
+                            }
+                        };
+                        rdg(0, aa, ax);
+                        for (int g = 0; g < groups; g += 2) {
+                            rdg(g + 1, ba, bx);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) acc = fma(aa[u], ax[u], acc);
+                            rdg(g + 2, aa, ax);
+                            if (g + 1 < groups) {
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) acc = fma(ba[u], bx[u], acc);
+                            }
+                        }
                     }
                     done += 64;
                     ++slot;
                 } while (done < len);
-                const double res = (bd.x - acc) / bd.y;
-                unsigned long long out = (unsigned long long)__double_as_longlong(res);
-                if (res != res) out = kCanonNaN; // never publish the sentinel (or the tag) pattern
-                p3 = p2; p2 = p1; p1 = out;
+                {   // optimistic look at the next row (valid if the watermark, read first, covers its slot)
+                    const unsigned wmn = lds_acquire(&L.ctl[C_WM]);
+                    len_n = L.rlen[(j + 1) & (kRowRing - 1)];
+                    bd_n = L.rbd[(j + 1) & (kRowRing - 1)];
+                    E_n = L.ent[slot & (kSlots - 1)][lane];
+                    asm volatile("" ::: "memory");
+                    wm = wmn;
+                }
+                unsigned long long out = 0ull;
                 if (lane == 0) {
+                    const double res = (bd.x - acc) / bd.y;
+                    out = (unsigned long long)__double_as_longlong(res);
+                    if (res != res) out = kCanonNaN; // never publish the sentinel (or the tag) pattern
                     __hip_atomic_store(&a.xs[r], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1: the flag IS the data
                     a.x[r] = __longlong_as_double((long long)out);
                     __hip_atomic_store(&L.res[r & (kMaxChain - 1)], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     lds_release(&L.ctl[C_DONE], slot);
                     lds_release(&L.ctl[C_ROWS_DONE], (unsigned)(j + 1));
                 }
+                out = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(out >> 32)) << 32) |
+                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)out);
+                p3 = p2; p2 = p1; p1 = out;
+                wm = (unsigned)__builtin_amdgcn_readfirstlane((int)wm);
+                have_n = j + 1 < m && (int)(wm - (slot + 1u)) >= 0;
             }
             if (lane == 0) lds_release(&L.ctl[C_CHAIN_DONE], gen);
         }
@@ -583,9 +679,16 @@ bis_status bis_trsv_chain_build(bis_ctx *ctx, const bis_mat *T, bool backward, c
 bis_status bis_trsv_chain_solve(bis_ctx *ctx, const bis_mat *T, bis_trsv_chain *p, double *x, const double *D, const double *b) {
     const int fill_grid = (int)std::min<int64_t>((p->n + 1 + 255) / 256, 2048);
     hipLaunchKernelGGL(chain_fill_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, p->xs, p->n + 1, p->ticket);
-    ChainArgs a{T->row_ptr, T->col, T->val, p->c_row0, p->c_len, D, b, x, p->xs, p->ticket, ctx->fault_dev, ctx->spmv_stop, p->n, p->n_chains};
+    ChainArgs a{T->row_ptr, T->col, T->val, p->c_row0, p->c_len, D, b, x, p->xs, p->ticket, ctx->fault_dev, ctx->spmv_stop, p->n, p->n_chains,
+                bis_opts().trsv_chain_idle >= 0 ? bis_opts().trsv_chain_idle : 2, bis_opts().trsv_chain_pause >= 0 ? bis_opts().trsv_chain_pause : 8};
     // every wave of the grid must be resident (the progress argument counts them): the grid is what the occupancy query allows
-    const int grid = chain_grid(ctx, T->rp64, p->backward != 0);
+    int grid = chain_grid(ctx, T->rp64, p->backward != 0);
+    // fewer pairs = fewer feeders waiting far ahead of the wavefront; never fewer than the progress argument needs (per queue: the
+    // chains that may straddle a level, plus one that is free)
+    // (measured, pairs per queue -> ms per sweep: fem:40,40,41 [60 straddle] 128: 0.92, 320: 1.12; fem:80,80,81 [229] 256: 2.44, 320: 2.62;
+    // unstr:80,80,80 RCM-ordered [88 forward / 220 backward] 128 (222 backward): 6.6 / 7.0, 256: 7.2 / 7.0, 320: 7.7 / 7.5)
+    const int pairs = bis_opts().trsv_chain_pairs > 0 ? bis_opts().trsv_chain_pairs : std::max(64, p->max_straddle + p->max_straddle / 2 + 32);
+    grid = std::max(std::min(grid, (pairs * kQueues / 2 + 3) & ~3), std::min(grid, ((p->max_straddle + 2) * kQueues / 2 + 3) & ~3));
     if (T->rp64) {
         if (p->backward) hipLaunchKernelGGL((trsv_chain_kernel<int64_t, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL((trsv_chain_kernel<int64_t, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
