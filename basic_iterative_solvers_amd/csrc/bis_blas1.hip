@@ -289,6 +289,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_wave")) o.trsv_wave = value;
     else if (!strcmp(name, "trsv_host_analysis")) o.trsv_host_analysis = value;
     else if (!strcmp(name, "ilu0_wave")) o.ilu0_wave = value;
+    else if (!strcmp(name, "ilu0_persistent")) o.ilu0_persistent = value;
     else if (!strcmp(name, "trsv_by_pos")) o.trsv_by_pos = value;
     else if (!strcmp(name, "spmv_packed")) o.spmv_packed = value;
     else if (!strcmp(name, "spmv_lds_pad")) o.spmv_lds_pad = value;

@@ -48,7 +48,7 @@ struct bis_cg {
     int hist_cap = 0;
     int enqueued = 0;
     bool initialised = false; // bis_cg_init has run: p0 and (r,z) were made with the preconditioner set at that time
-    unsigned *counters = nullptr; // device: arrival tickets of the last-arriver reductions ([0] pap, [1] pass B)
+    unsigned *counters = nullptr; // device: arrival tickets of the last-arriver reductions ([0] pap, [1] pass B, [4...] pass B's per-group counters)
     // general preconditioner (bis_cg_set_preconditioner): z = M^-1 r through bis_apply_preconditioner
     int pc = -1;
     const bis_mat *pcL = nullptr, *pcU = nullptr;
@@ -83,6 +83,23 @@ __device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned n_groups
     const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t != n_groups - 1) return false;
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // next use: after a kernel boundary
+    return true;
+}
+
+// The same with a counter per 16 workgroups under one top counter.  Tickets on ONE address serialise at ~11.4 ns each (measured:
+// the sweeps' ticket counter): 2048 workgroups of pass B cost 23 us in tickets alone -- nothing next to 70 us of streaming
+// on 16.8 M rows, but most of the pass on one rank's 1/8 share of a strong-scaled problem (34 us measured for 2 M rows against
+// 10 us of bandwidth time: profiles/r04_b_dist_gap_slab32.txt).  Two levels: 16 + n/16 tickets on the critical path.
+constexpr unsigned kArriveGroup = 16;
+constexpr unsigned kArriveSubs = 2048 / kArriveGroup; // kMaxReduceBlocks workgroups at most
+__device__ __forceinline__ bool arrive_last2(unsigned *top, unsigned *sub, unsigned block, unsigned n_blocks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the published partials have left this CU
+    const unsigned g = block / kArriveGroup;
+    const unsigned n_in = min(kArriveGroup, n_blocks - g * kArriveGroup), n_groups = (n_blocks + kArriveGroup - 1) / kArriveGroup;
+    if (__hip_atomic_fetch_add(&sub[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != n_in - 1) return false;
+    __hip_atomic_store(&sub[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != n_groups - 1) return false;
+    __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // next use: after a kernel boundary
     return true;
 }
 
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, double *sc, in
     if (threadIdx.x == 0) {
         publish(partials + blockIdx.x, s0);
         publish(partials + stride + blockIdx.x, s1);
-        last = arrive_last(counter, gridDim.x);
+        last = arrive_last2(counter, counter + 3, blockIdx.x, gridDim.x);
     }
     __syncthreads();
     if (!last) return;
@@ -276,8 +293,8 @@ static bis_status cg_create_common(bis_ctx *ctx, bis_dist *dist, const bis_mat *
     if (st == BIS_OK) st = bis_vec_alloc(ctx, kPapBlocks, &cg->pap_stage);
     if (st == BIS_OK) st = bis_vec_alloc(ctx, cg->hist_cap, &cg->hist);
     if (st == BIS_OK && hipMalloc(&cg->flags, sizeof(int) * 4) != hipSuccess) st = BIS_ERR_HIP;
-    if (st == BIS_OK && (hipMalloc(&cg->counters, sizeof(unsigned) * 4) != hipSuccess ||
-                         hipMemsetAsync(cg->counters, 0, sizeof(unsigned) * 4, ctx->stream) != hipSuccess)) st = BIS_ERR_HIP;
+    if (st == BIS_OK && (hipMalloc(&cg->counters, sizeof(unsigned) * (4 + kArriveSubs)) != hipSuccess ||
+                         hipMemsetAsync(cg->counters, 0, sizeof(unsigned) * (4 + kArriveSubs), ctx->stream) != hipSuccess)) st = BIS_ERR_HIP;
     if (st != BIS_OK) { bis_cg_destroy(ctx, cg); return st; }
     if (!A_D) cg->z = cg->r; // z aliases r without a preconditioner
     *out = cg;

@@ -206,6 +206,96 @@ __global__ __launch_bounds__(256) void ilu0_level_wave_kernel(const RP *__restri
     if (lane == 0) { U_D[i] = u_diag; L_D[i] = 1.0; }
 }
 
+// The same elimination as ONE launch (persistent grid).  With a launch per level a row cannot begin before the whole previous level
+// has ended, although all but its last few eliminations need rows that were finished long ago: a level then costs a row's full time
+// (~35 eliminations of two dependent trips to memory each: 48 us per level measured on the config-5 stand-in, 1674 levels = 80 ms).
+// Here the rows are dealt round robin, in level order, to the resident waves (static, like sptrsv_wave_kernel: a wave walks its
+// positions in ascending order and waits only for rows at smaller positions, so every position completes provided the whole grid
+// is resident); a wave waits PER ELIMINATION for the flag of the row it needs -- set by that row's wave after its stores have
+// drained -- so only the eliminations that really are on the dependency chain wait.  Hand-off form: the finished row's values and
+// pivot are written with sc1 (write-through) stores, `s_waitcnt vmcnt(0)`, then the sc1 flag; the reader polls the flag with sc1
+// loads and reads the row with sc1 loads (MI355X_MICROARCH.md, hand-offs measured with sc1 loads in place of the acquire).  The
+// arithmetic is the level kernel's, entry for entry.
+constexpr unsigned kIluSpin = 1u << 21;
+template <typename RP>
+__global__ __launch_bounds__(256, 4) void ilu0_persistent_kernel(const RP *__restrict__ rp, const int32_t *__restrict__ wcol, double *wval,
+                                                                 const int64_t *__restrict__ dpos, const int64_t *__restrict__ ustart,
+                                                                 const int32_t *__restrict__ perm, int64_t n, double pivot_tol,
+                                                                 double pivot_repl, double *U_D, double *L_D, int max_row, int *flag,
+                                                                 unsigned *fault) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ilu_smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *lval = reinterpret_cast<double *>(ilu_smem) + (size_t)wave * max_row;
+    int32_t *lcol = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(ilu_smem) + (size_t)4 * max_row) + (size_t)wave * max_row;
+    unsigned long long *wv = reinterpret_cast<unsigned long long *>(wval);
+    unsigned long long *ud = reinterpret_cast<unsigned long long *>(U_D);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    bool aborted = false;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n; t += n_waves) {
+        const int i = perm[t];
+        const int64_t s = rp[i], e = rp[i + 1];
+        const int len = (int)(e - s);
+        for (int q = lane; q < len; q += 64) { lcol[q] = wcol[s + q]; lval[q] = wval[s + q]; } // (the row's own entries: nobody else writes them)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int p = 0; p < len; ++p) {
+            const int k = lcol[p]; // uniform
+            if (k >= i) break;
+            // row k must be finished: its wave set the flag after its stores had drained
+            if (!aborted) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&flag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    if (++spins > kIluSpin || ((spins & 1023u) == 0u && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
+                        aborted = true; // bounded: the factors are wrong from here on, the context's fault word says so
+                        if (lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const double pivot = __longlong_as_double((long long)__hip_atomic_load(&ud[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (fabs(pivot) < 1e-16) continue;
+            const double factor = lval[p] / pivot; // every lane computes the same value
+            const int64_t us = ustart[k], ue = (int64_t)rp[k + 1];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all lanes have read lval[p] before it is overwritten
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) lval[p] = factor;
+            for (int64_t q = us + lane; q < ue; q += 64) {
+                const int j = wcol[q];
+                const double u = __longlong_as_double((long long)__hip_atomic_load(&wv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                int lo = p + 1, hi = len; // j > k: search the rest of row i
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (lcol[mid] < j) lo = mid + 1; else hi = mid;
+                }
+                if (lo < len && lcol[lo] == j) {
+                    const double w = lval[lo];
+                    if (w != 0.0) lval[lo] = fma(-factor, u, w);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // updates visible to the next elimination
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int64_t dp = dpos[i];
+        double u_diag = dp >= 0 ? lval[dp - s] : 0.0;
+        if (fabs(u_diag) < pivot_tol) u_diag = (u_diag >= 0 ? 1.0 : -1.0) * pivot_repl;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0 && dp >= 0) lval[dp - s] = u_diag;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int q = lane; q < len; q += 64)
+            __hip_atomic_store(&wv[s + q], (unsigned long long)__double_as_longlong(lval[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(&ud[i], (unsigned long long)__double_as_longlong(u_diag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L_D[i] = 1.0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every lane's stores of this row have left before the flag does
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(&flag[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // rows of the sorted copy with a repeated column: the wave-per-row kernel locates ONE entry per column by binary search,
 // the reference's serial loop updates every copy -- such matrices take the lane-per-row kernel
 template <typename RP>
@@ -265,11 +355,38 @@ bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot
     const std::vector<int64_t> *level_ptr = nullptr;
     const int32_t *perm = nullptr;
     st = bis_trsv_level_sets(ctx, Lp, &level_ptr, &perm);
-    if (st == BIS_OK) {
+    const bool wave_ok = W->max_row_nnz <= kIluMaxRow && bis_opts().ilu0_wave != 0 && !has_dups;
+    bool done = false;
+    if (st == BIS_OK && wave_ok && bis_opts().ilu0_persistent != 0 && n > 0) {
+        // one launch: rows in level order over a resident grid, a flag per finished row (see the kernel)
+        const int mr = std::max(W->max_row_nnz, 1);
+        const size_t smem = (size_t)4 * mr * (sizeof(double) + sizeof(int32_t));
+        int nb = 0;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ilu0_persistent_kernel<RP>, 256, smem);
+        (void)hipGetLastError();
+        int *flag = nullptr;
+        if (oe == hipSuccess && nb > 0 && hipMalloc(&flag, sizeof(int) * (size_t)n) == hipSuccess) {
+            const int share = std::max(1, bis_opts().device_share);
+            const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->n_cus * std::min(nb, 4) / share));
+            hipMemsetAsync(flag, 0, sizeof(int) * (size_t)n, ctx->stream);
+            hipLaunchKernelGGL(ilu0_persistent_kernel<RP>, dim3((unsigned)grid), dim3(256), smem, ctx->stream, rp, W->col, W->val, dpos, ustart,
+                               perm, n, pivot_tol, pivot_repl, U_D, L_D, mr, flag, ctx->fault_dev);
+            hipError_t le = hipGetLastError();
+            if (le == hipSuccess) le = hipStreamSynchronize(ctx->stream);
+            hipFree(flag);
+            if (le != hipSuccess) { ctx->err = std::string("bis_mat_ilu0: ") + hipGetErrorString(le); st = BIS_ERR_HIP; }
+            else if (bis_status fs = bis_fault_check(ctx)) st = fs;
+            done = true;
+        } else {
+            (void)hipGetLastError();
+            hipFree(flag);
+        }
+    }
+    if (st == BIS_OK && !done) {
         const int nl = (int)level_ptr->size() - 1;
         for (int l = 0; l < nl; ++l) {
             const int64_t lo = (*level_ptr)[l], hi = (*level_ptr)[l + 1];
-            if (W->max_row_nnz <= kIluMaxRow && bis_opts().ilu0_wave != 0 && !has_dups) {
+            if (wave_ok) {
                 const int mr = std::max(W->max_row_nnz, 1);
                 hipLaunchKernelGGL(ilu0_level_wave_kernel<RP>, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256),
                                    (size_t)4 * mr * (sizeof(double) + sizeof(int32_t)), ctx->stream, rp, W->col,

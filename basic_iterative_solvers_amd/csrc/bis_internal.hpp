@@ -66,6 +66,7 @@ struct bis_options {
     int spmv_xcd_remap = -1; // 1: each XCD sweeps its own slab of row blocks (default: blockIdx order)
     int trsv_grid = -1;    // -1: automatic
     int ilu0_wave = -1;    // 0: lane-per-row ILU(0) level kernel (default: wave per row)
+    int ilu0_persistent = -1; // 0: a launch per level (default: one persistent launch, a flag per finished row)
     int trsv_host_analysis = -1; // 1: level analysis on the host (default: on the device)
     int trsv_wave = -1;    // 1: one wave per row in the sync-free sweeps (default for rows > 16)
     int trsv_batch = -1;   // dependencies polled per round trip (4, 8, 16; -1: by row length)
@@ -81,9 +82,9 @@ struct bis_options {
     int grid_autodetect = -1; // bis_mat_create: recognise a stencil on a structured grid from the offsets of a few rows (0: off)
     int trsv_chain = -1;    // natural-order sweeps of matrices without a grid: -1 = the chained sweep (bis_trsv_chain.hip) where its plan applies (chains of >= 3 rows on
                             // average, fewer chains straddling a level than resident waves), 1 = also with shorter chains, 0 = level-scheduled kernels only
-    int trsv_chain_idle = -1;  // chained sweep: poll rounds without a delivery after which a feeder polls one word only (default 2)
+    int trsv_chain_idle = -1;  // chained sweep: poll rounds without a delivery after which a feeder polls one word only (default: never -- measured slower with the pairs kept near the bound)
     int trsv_chain_pause = -1; // ... and pauses up to this many x 256 cycles between its looks (default 8)
-    int trsv_chain_pairs = -1; // wave pairs per ticket queue (default: all that are resident)
+    int trsv_chain_pairs = -1; // wave pairs per ticket queue (default: the plan's straddle bound + 1/8 + 8)
     int trsv_tiled = -1;    // natural-order sweeps: -1 = tiled sweep (bis_trsv_tiled.hip) where its device plan applies (grid hint), 1 = also with the host plan, 2 = host plan only, 0 = level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)
     int trsv_tile_wgs = -1;  // resident workgroups per CU of the tiled sweep (default: what fits, 3)

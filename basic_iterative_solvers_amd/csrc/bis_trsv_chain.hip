@@ -680,14 +680,16 @@ bis_status bis_trsv_chain_solve(bis_ctx *ctx, const bis_mat *T, bis_trsv_chain *
     const int fill_grid = (int)std::min<int64_t>((p->n + 1 + 255) / 256, 2048);
     hipLaunchKernelGGL(chain_fill_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, p->xs, p->n + 1, p->ticket);
     ChainArgs a{T->row_ptr, T->col, T->val, p->c_row0, p->c_len, D, b, x, p->xs, p->ticket, ctx->fault_dev, ctx->spmv_stop, p->n, p->n_chains,
-                bis_opts().trsv_chain_idle >= 0 ? bis_opts().trsv_chain_idle : 2, bis_opts().trsv_chain_pause >= 0 ? bis_opts().trsv_chain_pause : 8};
+                bis_opts().trsv_chain_idle >= 0 ? bis_opts().trsv_chain_idle : (1 << 30), bis_opts().trsv_chain_pause >= 0 ? bis_opts().trsv_chain_pause : 8};
     // every wave of the grid must be resident (the progress argument counts them): the grid is what the occupancy query allows
     int grid = chain_grid(ctx, T->rp64, p->backward != 0);
     // fewer pairs = fewer feeders waiting far ahead of the wavefront; never fewer than the progress argument needs (per queue: the
     // chains that may straddle a level, plus one that is free)
     // (measured, pairs per queue -> ms per sweep: fem:40,40,41 [60 straddle] 128: 0.92, 320: 1.12; fem:80,80,81 [229] 256: 2.44, 320: 2.62;
     // unstr:80,80,80 RCM-ordered [88 forward / 220 backward] 128 (222 backward): 6.6 / 7.0, 256: 7.2 / 7.0, 320: 7.7 / 7.5)
-    const int pairs = bis_opts().trsv_chain_pairs > 0 ? bis_opts().trsv_chain_pairs : std::max(64, p->max_straddle + p->max_straddle / 2 + 32);
+    // With few pairs beyond the bound, and every feeder polling all its pending operands all the time (no idle mode):
+    // fem:80,80,81 231 pairs: 2.05 ms (320 pairs with the idle mode 2.62); unstr:80,80,80 RCM 90 / 222 pairs: 6.35 / 7.33 ms (6.9 / 7.7).
+    const int pairs = bis_opts().trsv_chain_pairs > 0 ? bis_opts().trsv_chain_pairs : p->max_straddle + p->max_straddle / 8 + 8;
     grid = std::max(std::min(grid, (pairs * kQueues / 2 + 3) & ~3), std::min(grid, ((p->max_straddle + 2) * kQueues / 2 + 3) & ~3));
     if (T->rp64) {
         if (p->backward) hipLaunchKernelGGL((trsv_chain_kernel<int64_t, true>), dim3(grid), dim3(256), 0, ctx->stream, a);

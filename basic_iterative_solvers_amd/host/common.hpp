@@ -83,7 +83,7 @@ struct Args {
     std::string dump_x;             // -dump-x FILE: write x* (natural row order, also after -perm)
     std::string crs_cache;          // -cache FILE: binary CRS next to a .mtx input (read if present, else written)
     bool perm_host = false;         // -perm-host: colour and permute on the host (fallback path)
-    int trsv_mode = -1;             // -trsv tiled|level: natural-order sweeps with the tiled kernel also where its plan is built on the host / never (default: tiled where the matrix has a grid hint)
+    int trsv_mode = -1;             // -trsv tiled|level|chain|wave: natural-order sweeps with the tiled kernel also where its plan is built on the host / never (default: tiled where the matrix has a grid hint)
     long long grid_hint[4] = {0, 0, 0, 0}; // -grid NX,NY,NZ[,DOF]: a matrix read from a file is a stencil on this grid, x fastest (bis_mat_set_grid_hint)
     int device = 0;
 };

@@ -52,7 +52,11 @@ int main(int argc, char *argv[]) {
     Args cli_args;
     parse_cli(&cli_args, argc, argv);
     bis::init(cli_args.device);
-    if (cli_args.trsv_mode >= 0) bis_set_option("trsv_tiled", cli_args.trsv_mode);
+    // -trsv tiled | level (no tiled sweep: chained where its plan applies, else level-scheduled) | chain (no tiled sweep, chained also with
+    // short chains) | wave (neither: the level-scheduled kernels of round 1)
+    if (cli_args.trsv_mode == 0 || cli_args.trsv_mode == 1) bis_set_option("trsv_tiled", cli_args.trsv_mode);
+    if (cli_args.trsv_mode == 2) { bis_set_option("trsv_tiled", 0); bis_set_option("trsv_chain", 1); }
+    if (cli_args.trsv_mode == 3) { bis_set_option("trsv_tiled", 0); bis_set_option("trsv_chain", 0); }
     TIME(&timers, "total", run(&cli_args, &timers))
     print_timers(&cli_args, &timers);
     bis::shutdown();

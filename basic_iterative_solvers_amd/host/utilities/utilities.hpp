@@ -63,7 +63,7 @@ inline void parse_cli(Args *a, int argc, char *argv[]) {
         else if (arg == "-hostscalars") a->host_scalars = true;
         else if (arg == "-trsv" && i + 1 < argc) {
             const std::string m = argv[++i];
-            a->trsv_mode = m == "tiled" ? 1 : m == "level" ? 0 : -1;
+            a->trsv_mode = m == "tiled" ? 1 : m == "level" ? 0 : m == "chain" ? 2 : m == "wave" ? 3 : -1;
         } else if (arg == "-grid" && i + 1 < argc) {
             a->grid_hint[3] = 1;
             if (sscanf(argv[++i], "%lld,%lld,%lld,%lld", &a->grid_hint[0], &a->grid_hint[1], &a->grid_hint[2], &a->grid_hint[3]) < 3) {

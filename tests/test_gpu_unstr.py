@@ -125,16 +125,22 @@ def test_nongrid_sweep_kernels_at_size_bit_exact(ctx, oracle, order, mode):
         m.free()
 
 
+@pytest.mark.parametrize("persistent", [-1, 0])
 @pytest.mark.parametrize("order", ["asis", "rcm"])
-def test_nongrid_ilu0_at_size_vs_oracle(ctx, oracle, order):
-    """Device ILU(0) (level-scheduled, one wave per row) of the same 101,376-row input against the serial
+def test_nongrid_ilu0_at_size_vs_oracle(ctx, oracle, order, persistent):
+    """Device ILU(0) (rows in level order, one wave per row: the persistent one-launch form with a flag per finished
+    row -- the default -- and the launch-per-level form) of the same 101,376-row input against the serial
     factor_ILU0_old restatement: pattern bit-exact, values <= 1e-13; then the ILU(0) preconditioner apply
     (kernels.hpp:386-394) through the general sweeps, bit-exact against the oracle on the DEVICE's factors."""
     shape = (32, 32, 33)
     A, dA = _sweep_case(ctx, oracle, shape, order)
     n = A.n_rows
     iLs, iL_D, iUs, iU_D = oracle.factor_ilu0(A)
-    fLs, fL_D, fUs, fU_D = ctx.ilu0(dA)
+    ctx.set_option("ilu0_persistent", persistent)
+    try:
+        fLs, fL_D, fUs, fU_D = ctx.ilu0(dA)
+    finally:
+        ctx.set_option("ilu0_persistent", -1)
     rp, col, val = fUs.download()
     assert np.array_equal(rp, iUs.row_ptr) and np.array_equal(col, iUs.col) and relerr(val, iUs.val) <= KTOL
     U_dev = type(iUs)(n, rp, col, val)

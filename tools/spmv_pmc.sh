@@ -26,6 +26,8 @@ rm -rf $O/trace
 g=0
 for grp in "${GROUPS_[@]}"; do
   g=$((g+1))
+  # PMC_GROUPS="1 2 10": only those counter groups (default: all)
+  if [ -n "$PMC_GROUPS" ] && ! echo " $PMC_GROUPS " | grep -q " $g "; then continue; fi
   timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $O/g$g -o r -- python3 $R/tools/spmv_probe.py $KIND $SIZE 20 $VD > $O/g$g.log 2>&1 || echo "pmc group $g failed: $grp"
   f=$(find $O/g$g -name "*counter_collection.csv")
   [ -n "$f" ] && python3 $R/tools/pmc_summary_csv.py $f > $O/pmc_g$g.csv
