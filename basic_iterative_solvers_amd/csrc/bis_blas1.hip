@@ -309,6 +309,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "trsv_chain_idle")) o.trsv_chain_idle = value;
     else if (!strcmp(name, "trsv_chain_pause")) o.trsv_chain_pause = value;
     else if (!strcmp(name, "trsv_chain_pairs")) o.trsv_chain_pairs = value;
+    else if (!strcmp(name, "trsv_chain_prefix")) o.trsv_chain_prefix = value;
     else if (!strcmp(name, "trsv_tile_rows")) o.trsv_tile_rows = value;
     else if (!strcmp(name, "trsv_tile_wgs")) o.trsv_tile_wgs = value;
     else if (!strcmp(name, "trsv_tile_edge")) o.trsv_tile_edge = value;

@@ -84,6 +84,7 @@ struct bis_options {
                             // average, fewer chains straddling a level than resident waves), 1 = also with shorter chains, 0 = level-scheduled kernels only
     int trsv_chain_idle = -1;  // chained sweep: poll rounds without a delivery after which a feeder polls one word only (default: never -- measured slower with the pairs kept near the bound)
     int trsv_chain_pause = -1; // ... and pauses up to this many x 256 cycles between its looks (default 8)
+    int trsv_chain_prefix = -1; // 1: the feeder sums the part of a row's fma chain before its first chain-internal operand (default off: measured slower -- the feeder then paces the pair: fem:80,80,81 forward 2.55 -> 3.0 ms)
     int trsv_chain_pairs = -1; // wave pairs per ticket queue (default: the plan's straddle bound + 1/8 + 8)
     int trsv_tiled = -1;    // natural-order sweeps: -1 = tiled sweep (bis_trsv_tiled.hip) where its device plan applies (grid hint), 1 = also with the host plan, 2 = host plan only, 0 = level-scheduled kernels
     int trsv_tile_rows = -1; // rows per tile at most (default 8192 for rows of <= 8 entries, else 2048)

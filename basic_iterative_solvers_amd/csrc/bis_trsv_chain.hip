@@ -70,7 +70,7 @@ constexpr int kRowBatch = 32;         // rows whose b / D / length the feeder fe
 constexpr int kRowRing = 2 * kRowBatch;
 constexpr unsigned kSpinMem = 1u << 20;  // polls of a memory word before a wave gives up (about a second)
 constexpr unsigned kSpinLds = 1u << 26;  // polls of an LDS word (several seconds: longer than the feeder's own budget)
-constexpr int kBlocksPerCU = 5;       // 20.8 KiB of LDS per workgroup; 5 per CU leaves each wave 102 VGPRs (at 7 the consumer spilled its chain registers: a trip to memory per row)
+constexpr int kBlocksPerCU = 5;       // 23 KiB of LDS per workgroup; 4 per CU leaves each wave 128 VGPRs (with fewer the feeder, and at 7 per CU the consumer, spill: a trip to memory per row)
 
 enum { C_GEN = 0, C_ROW0, C_M, C_WM, C_DONE, C_ROWS_DONE, C_CHAIN_DONE, C_EXIT, C_N = 8 };
 
@@ -112,16 +112,21 @@ struct ChainArgs {
     int n_chains;
     int idle_rounds; // poll rounds without a delivery after which a feeder polls one word only
     int idle_cap;    // ... and pauses up to this many x 256 cycles between its looks
+    int prefix;      // 1: the feeder sums the entries before a row's first chain-internal operand
 };
 
 struct __attribute__((aligned(16))) Entry { double val; unsigned long long v; };
 
+constexpr bool kFeederPrefix = false;     // the feeder sums the part of a row's fma chain before its first chain-internal operand: built, bit-exact, and
+                                          // slower (the feeder then paces the pair: fem:80,80,81 forward 2.55 -> 3.0 ms) -- kept for the record, compiled out
+constexpr int kSlotLen = 72;              // 64 entries + a group of (0.0, 0.0) entries behind them: what a fma chain reads past a slot's end
 struct PairLds {
-    Entry ent[kSlots][64];                // the feeder's stream: value and operand of every entry, a slot per row segment
+    Entry ent[kSlots][kSlotLen];          // the feeder's stream: value and operand of every entry, a slot per row segment
     double2 rbd[kRowRing];                // per row: b, D
     int rlen[kRowRing];                   // per row: number of entries
     unsigned long long res[kMaxChain];    // the chain's own results, by row & (kMaxChain - 1) (consumer only)
-    Entry zero[8];                        // a group of (0.0, 0.0) entries: what the consumer's fma chain reads behind a slot's end
+    double pre_acc[kSlots];               // per slot: the fma chain over the entries before the first chain-internal operand (feeder) ...
+    int pre_q[kSlots];                    // ... and the index of that entry: where the consumer takes the chain up
     unsigned ctl[C_N];
 };
 
@@ -140,7 +145,10 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
     PairLds &L = lds2[wv >> 1];
     const bool feeder = (wv & 1) == 0;
     if (threadIdx.x < 2 * C_N) lds2[threadIdx.x / C_N].ctl[threadIdx.x % C_N] = 0u;
-    if (threadIdx.x >= 64 && threadIdx.x < 80) { Entry &z = lds2[(threadIdx.x - 64) / 8].zero[threadIdx.x & 7]; z.val = 0.0; z.v = 0ull; }
+    if (threadIdx.x < 2 * kSlots * 8) { // the padding group of every slot
+        Entry &z = lds2[threadIdx.x / (kSlots * 8)].ent[(threadIdx.x / 8) % kSlots][64 + (threadIdx.x & 7)];
+        z.val = 0.0; z.v = 0ull;
+    }
     __syncthreads(); // (the only barrier: from here on the two pairs of the workgroup run on their own)
     const RP *rp = (const RP *)a.row_ptr;
     const unsigned pair_id = blockIdx.x * 2u + (unsigned)(wv >> 1);
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                 };
                 // segments of this batch in order: (row j, first entry, entries in the segment)
                 int cur_j = 0, cur_off = 0; // next segment: row cur_j of the batch, entries from cur_off
-                struct Seg { int j, cnt; int64_t k0; };
+                struct Seg { int j, cnt, first; int64_t k0; };
                 auto next_seg = [&](Seg &sg) { // uniform; returns false when the batch is exhausted (the segment is then empty, addresses stay valid)
                     const bool have = cur_j < nb;
                     const int j = have ? cur_j : nb - 1;
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                     sg.j = j;
                     sg.k0 = s + (have ? cur_off : 0);
                     sg.cnt = have ? min(64, len - cur_off) : 0;
+                    sg.first = cur_off == 0 ? 1 : 0;
                     if (have) { cur_off += 64; if (cur_off >= len) { ++cur_j; cur_off = 0; } }
                     return have;
                 };
@@ -234,9 +243,14 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                         ext[g] = act && !internal[g];
                         raw[g] = __hip_atomic_load(&a.xs[ext[g] ? R[g].c : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    int qarr[kGroup]; // per slot: the first entry with a chain-internal operand (the row's length if there is none; 0 for the
+                                      // later segments of a long row, whose chain continues the previous segment's)
 #pragma unroll
-                    for (int g = 0; g < kGroup; ++g)
+                    for (int g = 0; g < kGroup; ++g) {
                         v[g] = internal[g] ? (((unsigned long long)kInternalTag << 32) | (unsigned)dist[g]) : ext[g] ? raw[g] : 0ull;
+                        const unsigned long long im = __ballot(internal[g]);
+                        qarr[g] = (kFeederPrefix && sg[g].first && a.prefix) ? (im ? (int)__builtin_ctzll(im) : sg[g].cnt) : 0;
+                    }
                     // ring space: the slots this group takes must have been consumed
                     {
                         unsigned spins = 0;
@@ -261,14 +275,50 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                     unsigned spins = 0;
                     for (;;) {
                         bool progressed = false;
+                        int pub1 = pub;
 #pragma unroll
                         for (int g = 0; g < kGroup; ++g) {
-                            if (g == pub && g < n_seg && !__ballot(ext[g] && v[g] == kSentinel)) {
+                            if (g == pub1 && g < n_seg && !__ballot(ext[g] && v[g] == kSentinel)) {
                                 L.ent[(slots_pub + (unsigned)g) & (kSlots - 1)][lane].v = v[g];
-                                if (lane == 0) lds_release(&L.ctl[C_WM], slots_pub + (unsigned)g + 1u);
-                                ++pub;
-                                progressed = true;
+                                ++pub1;
                             }
+                        }
+                        if (pub1 > pub) {
+                            // The part of each row's fma chain that needs nothing of this chain -- the entries before its first chain-internal
+                            // operand: in a forward sweep over ascending columns all but the last few -- is summed HERE, off the consumer's
+                            // critical path: lane j takes the j-th slot of this round, the slots' chains run side by side (same CRS order,
+                            // same fma per entry: the consumer continues where this stops).
+                            int myq = 0, maxq = 0;
+                            unsigned myslot = 0;
+#pragma unroll
+                            for (int g = 0; g < kGroup; ++g) {
+                                if (g >= pub && g < pub1) {
+                                    maxq = max(maxq, qarr[g]);
+                                    if (lane == g - pub) { myq = qarr[g]; myslot = (slots_pub + (unsigned)g) & (kSlots - 1); }
+                                }
+                            }
+                            asm volatile("" ::: "memory");
+                            if (kFeederPrefix && lane < pub1 - pub) {
+                                double acc = 0.0;
+                                typedef double v2d_lds __attribute__((ext_vector_type(2)));
+                                const volatile __attribute__((address_space(3))) v2d_lds *q =
+                                    (const volatile __attribute__((address_space(3))) v2d_lds *)&L.ent[myslot][0];
+                                for (int i0 = 0; i0 < maxq; i0 += 4) {
+                                    v2d_lds e[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) e[u] = q[i0 + u];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        const double t = fma(e[u].x, e[u].y, acc);
+                                        acc = i0 + u < myq ? t : acc;
+                                    }
+                                }
+                                L.pre_acc[myslot] = acc;
+                                L.pre_q[myslot] = myq;
+                            }
+                            if (lane == 0) lds_release(&L.ctl[C_WM], slots_pub + (unsigned)pub1);
+                            pub = pub1;
+                            progressed = true;
                         }
                         if (pub >= n_seg) break;
                         idle = (progressed || delivered) ? 0 : idle + 1; // (a delivery that does not complete a slot yet still says the wavefront is here)
@@ -355,27 +405,30 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                     __builtin_amdgcn_s_sleep(1);
                 }
             };
-            // (the next row's length, b / D and first entries are read while this row is divided and published: used if they were there)
+            // (the next row's length, b / D, prefix and first entries are read while this row is divided and published: used if they were there)
             bool have_n = false;
-            int len_n = 0;
+            int len_n = 0, q_n = 0;
             double2 bd_n = make_double2(0.0, 1.0);
-            Entry E_n;
-            E_n.val = 0.0; E_n.v = 0ull;
+            double acc_n = 0.0;
+            unsigned long long ev_n = 0ull;
             for (int j = 0; j < m; ++j) {
                 const int r = BACKWARD ? row0 - j : row0 + j;
-                // the row's length, b / D and this lane's entry of its first slot are read TOGETHER with the watermark that says whether
-                // they are there (the LDS runs a wave's reads in order: a watermark that covers the slot was read before data that is
-                // then valid) -- one LDS round trip per row instead of three
-                int len = len_n;
+                // the row's length, b / D, the feeder's prefix of its fma chain and this lane's operand of its first slot are read TOGETHER with
+                // the watermark that says whether they are there (the LDS runs a wave's reads in order: a watermark that covers the slot was
+                // read before data that is then valid) -- one LDS round trip per row
+                int len = len_n, q0 = q_n;
                 double2 bd = bd_n;
-                Entry E = E_n;
+                double acc = acc_n;
+                unsigned long long ev = ev_n;
                 if (!have_n) {
                     unsigned spins = 0;
                     for (;;) {
                         wm = lds_acquire(&L.ctl[C_WM]);
                         len = L.rlen[j & (kRowRing - 1)];
                         bd = L.rbd[j & (kRowRing - 1)];
-                        E = L.ent[slot & (kSlots - 1)][lane];
+                        if (kFeederPrefix) { acc = L.pre_acc[slot & (kSlots - 1)]; q0 = L.pre_q[slot & (kSlots - 1)]; }
+                        else { acc = 0.0; q0 = 0; }
+                        ev = L.ent[slot & (kSlots - 1)][lane].v;
                         asm volatile("" ::: "memory");
                         wm = (unsigned)__builtin_amdgcn_readfirstlane((int)wm);
                         if ((int)(wm - (slot + 1u)) >= 0) break;
@@ -384,58 +437,51 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                     }
                 }
                 len = __builtin_amdgcn_readfirstlane(len);
-                double acc = 0.0;
+                q0 = __builtin_amdgcn_readfirstlane(q0);
                 int done = 0;
                 do { // a slot per 64 entries (at least one per row)
-                    Entry (&S)[64] = L.ent[slot & (kSlots - 1)];
-                    if (done > 0) { wait_slot(slot + 1u); E = S[lane]; }
+                    Entry (&S)[kSlotLen] = L.ent[slot & (kSlots - 1)];
+                    if (done > 0) { wait_slot(slot + 1u); ev = S[lane].v; q0 = 0; }
                     const int cnt = min(64, len - done);
-                    // operands this chain produced itself (tagged by the feeder): the last three from registers, older ones from the ring --
-                    // resolved by the lanes that hold them and written back into the slot
-                    if ((unsigned)(E.v >> 32) == kInternalTag) {
-                        const int dist = (int)(unsigned)E.v;
+                    // Operands this chain produced itself carry the feeder's tag and how many rows back they were made: the last three are in
+                    // registers (p1..p3), older ones in the ring of the chain's results; the lanes that hold them write them into the slot.
+                    // (Picking them inside the one-lane chain instead -- a compare and a few selects per entry -- made every entry cost 64 ns:
+                    // a lone lane's instruction issue, not the fma's latency, then paces the chain.)
+                    if ((unsigned)(ev >> 32) == kInternalTag) {
+                        const int dist = (int)(unsigned)ev;
                         const int orow = BACKWARD ? r + dist : r - dist;
                         const unsigned long long w = dist == 1 ? p1 : dist == 2 ? p2 : dist == 3 ? p3
                                                      : __hip_atomic_load(&L.res[orow & (kMaxChain - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_store(&S[lane].v, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     asm volatile("" ::: "memory");
-                    // acc = fma(a_i, x_i, acc) in CRS order -- the reference's chain exactly -- by ONE lane, reading entry after entry from the
-                    // slot (eight entries in flight ahead of the eight being summed; a one-lane LDS read moves 16 bytes, not a kilobyte: with
-                    // every lane reading the same entry the chain was bound by LDS bandwidth, 12.5 ns per entry; run across the lanes with
-                    // DPP moves -- each lane adding its entry to its left neighbour's sum -- it measured 32 ns per entry: tools/chain_probe.py).
-                    // The slot is padded with (0.0, 0.0) entries: fma(0, 0, acc) leaves acc as it is (acc is never -0.0: it starts at +0.0
-                    // and an exact cancellation rounds to +0.0), so the count is rounded up to the group and no step is predicated.
+                    // acc = fma(a_i, x_i, acc) in CRS order -- the reference's chain exactly -- by ONE lane, from entry q0 on (the feeder has
+                    // summed the entries before it), reading entry after entry from the slot: four entries in flight ahead of the four being
+                    // summed (a one-lane LDS read moves 16 bytes; the chain costs the dependent fma's latency, ~10 ns per entry: with DPP moves
+                    // across the lanes it measured 32 ns, with every lane reading every entry 12.5 ns -- tools/chain_probe.py).  The slot is
+                    // padded with (0.0, 0.0) entries: fma(0, 0, acc) leaves acc as it is (acc is never -0.0: it starts at +0.0 and an exact
+                    // cancellation rounds to +0.0), so the count is rounded up to the group and no step is predicated.
                     if (lane == 0) {
-                        const int groups = (cnt + 7) >> 3;
-                        // (relaxed ATOMIC reads: an ordinary read whose value is only used if the loop goes on is sunk behind the loop's exit
-                        // test by the compiler, i.e. issued when it is needed instead of a group ahead.  Two register sets, A and B, by
-                        // unrolling: no moves.  A group past the row's entries is zeros -- the slot's padding, or the pair's zero group behind
-                        // the slot's end -- and adds nothing.)
-                        double aa[8], ax[8], ba[8], bx[8];
-                        const Entry *Z = L.zero;
-                        auto rdg = [&](int g, double (&va)[8], double (&vx)[8]) {
-                            const Entry *base = g < 8 ? &S[g * 8] : Z;
-                            // (one 16-byte LDS read per entry; volatile so that it stays where it is written, in the LDS address space so
-                            // that it stays an LDS read)
-                            typedef double v2d_lds __attribute__((ext_vector_type(2)));
-                            const volatile __attribute__((address_space(3))) v2d_lds *q = (const volatile __attribute__((address_space(3))) v2d_lds *)base;
+                        typedef double v2d_lds __attribute__((ext_vector_type(2)));
+                        // (volatile so that the reads stay where they are written -- an ordinary read whose value is only used if the loop goes
+                        // on is sunk behind the loop's exit test --, in the LDS address space so that they stay LDS reads)
+                        const volatile __attribute__((address_space(3))) v2d_lds *q = (const volatile __attribute__((address_space(3))) v2d_lds *)&S[0];
+                        // (two register sets of eight entries, roles swapped by unrolling: eight fmas -- ~170 cycles of dependent latency -- cover
+                        // the LDS latency of the next eight reads; with sets of four the chain stalled on its reads)
+                        v2d_lds A8[8], B8[8];
+                        const int qs = kFeederPrefix ? q0 : 0;
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const v2d_lds e = q[u];
-                                va[u] = e.x;
-                                vx[u] = e.y;
-                            }
-                        };
-                        rdg(0, aa, ax);
-                        for (int g = 0; g < groups; g += 2) {
-                            rdg(g + 1, ba, bx);
+                        for (int u = 0; u < 8; ++u) A8[u] = q[qs + u];
+                        for (int e0 = qs; e0 < cnt; e0 += 16) {
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) acc = fma(aa[u], ax[u], acc);
-                            rdg(g + 2, aa, ax);
-                            if (g + 1 < groups) {
+                            for (int u = 0; u < 8; ++u) B8[u] = q[min(e0 + 8, 64) + u];
 #pragma unroll
-                                for (int u = 0; u < 8; ++u) acc = fma(ba[u], bx[u], acc);
+                            for (int u = 0; u < 8; ++u) acc = fma(A8[u].x, A8[u].y, acc);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) A8[u] = q[min(e0 + 16, 64) + u];
+                            if (e0 + 8 < cnt) {
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) acc = fma(B8[u].x, B8[u].y, acc);
                             }
                         }
                     }
@@ -446,7 +492,9 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                     const unsigned wmn = lds_acquire(&L.ctl[C_WM]);
                     len_n = L.rlen[(j + 1) & (kRowRing - 1)];
                     bd_n = L.rbd[(j + 1) & (kRowRing - 1)];
-                    E_n = L.ent[slot & (kSlots - 1)][lane];
+                    if (kFeederPrefix) { acc_n = L.pre_acc[slot & (kSlots - 1)]; q_n = L.pre_q[slot & (kSlots - 1)]; }
+                    else { acc_n = 0.0; q_n = 0; }
+                    ev_n = L.ent[slot & (kSlots - 1)][lane].v;
                     asm volatile("" ::: "memory");
                     wm = wmn;
                 }
@@ -680,7 +728,8 @@ bis_status bis_trsv_chain_solve(bis_ctx *ctx, const bis_mat *T, bis_trsv_chain *
     const int fill_grid = (int)std::min<int64_t>((p->n + 1 + 255) / 256, 2048);
     hipLaunchKernelGGL(chain_fill_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream, p->xs, p->n + 1, p->ticket);
     ChainArgs a{T->row_ptr, T->col, T->val, p->c_row0, p->c_len, D, b, x, p->xs, p->ticket, ctx->fault_dev, ctx->spmv_stop, p->n, p->n_chains,
-                bis_opts().trsv_chain_idle >= 0 ? bis_opts().trsv_chain_idle : (1 << 30), bis_opts().trsv_chain_pause >= 0 ? bis_opts().trsv_chain_pause : 8};
+                bis_opts().trsv_chain_idle >= 0 ? bis_opts().trsv_chain_idle : (1 << 30), bis_opts().trsv_chain_pause >= 0 ? bis_opts().trsv_chain_pause : 8,
+                bis_opts().trsv_chain_prefix > 0 ? 1 : 0};
     // every wave of the grid must be resident (the progress argument counts them): the grid is what the occupancy query allows
     int grid = chain_grid(ctx, T->rp64, p->backward != 0);
     // fewer pairs = fewer feeders waiting far ahead of the wavefront; never fewer than the progress argument needs (per queue: the

@@ -30,7 +30,7 @@ b, x = ctx.alloc(N), ctx.alloc(N)
 b.set(np.random.default_rng(1).uniform(-1, 1, N))
 ref = None
 for c in cfgs:
-    for k in ("tiled", "chain", "wave", "grid", "batch", "chain_idle", "chain_pause", "chain_pairs"):
+    for k in ("tiled", "chain", "wave", "grid", "batch", "chain_idle", "chain_pause", "chain_pairs", "chain_prefix"):
         lib.bis_set_option(("trsv_" + k).encode(), int(c.get(k, -1)))
     Ls, Us, D, Dinv = ctx.split_strict(A)  # plans are cached per matrix: fresh triangles per configuration
     t0 = time.perf_counter(); ctx.sptrsv(Ls, x, D, b); ctx.sync(); t_first = time.perf_counter() - t0
