@@ -29,6 +29,7 @@ struct bis_dist;
 bis_status bis_dist_spmv_launch(bis_ctx *ctx, bis_dist *d, double *x_ext, double *y, const double *w,
                                 int *n_partials);
 int bis_dist_total_blocks(const bis_dist *d);
+size_t bis_dist_partials_need(const bis_dist *d);
 int64_t bis_dist_n_local(const bis_dist *d);
 int64_t bis_dist_n_ext(const bis_dist *d);
 bis_status bis_dist_allreduce(bis_ctx *ctx, bis_dist *d, double *buf_dev, int count);
@@ -448,6 +449,7 @@ bis_status bis_cg_iterate(bis_ctx *ctx, bis_cg *cg, int n_iters) {
     const size_t nblk = cg->dist ? (size_t)bis_dist_total_blocks(cg->dist) : (size_t)cg->A->n_blocks_f;
     size_t need = std::max((size_t)2 * kMaxReduceBlocks, nblk * 16); // <= 16 waves per row block
     if (!cg->dist) need = std::max(need, (size_t)bis_spmv_sellwin_slices(cg->A)); // sliced-ELL form: one partial per 64 rows
+    else need = std::max(need, bis_dist_partials_need(cg->dist));                 // (three row ranges, each in its own format)
     bis_status st = bis_ensure_partials(ctx, need);
     if (st != BIS_OK) return st;
     ctx->spmv_stop = cg->flags;

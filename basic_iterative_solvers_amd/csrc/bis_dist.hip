@@ -777,6 +777,18 @@ bis_status bis_dist_spmv_launch(bis_ctx *ctx, bis_dist *d, double *x_ext, double
 }
 
 int bis_dist_total_blocks(const bis_dist *d) { return d->lo->n_blocks_f + d->mid->n_blocks_f + d->hi->n_blocks_f; }
+// Partials the fused dot of one distributed SpMV may write: the three row ranges lay theirs back to back, each with whatever its
+// stream format emits -- one per wave of a row block (<= 16 per block), one per 256-row block x 4 (lane-per-row dictionary form) or
+// one per 64-row slice rounded up to blocks of 512 rows (sliced-ELL form).  An upper bound over the formats, per range.
+size_t bis_dist_partials_need(const bis_dist *d) {
+    size_t tot = 0;
+    for (const bis_mat *v : {d->lo, d->mid, d->hi}) {
+        const size_t rows = (size_t)std::max<int64_t>(v->n_rows, 0);
+        const size_t sell = ((rows + 511) / 512) * 8 + 8, rowmajor = ((rows + 255) / 256) * 4 + 8, rowblock = (size_t)v->n_blocks_f * 16;
+        tot += std::max(sell, std::max(rowmajor, rowblock));
+    }
+    return tot;
+}
 int64_t bis_dist_n_local(const bis_dist *d) { return d->n_local; }
 int64_t bis_dist_n_ext(const bis_dist *d) { return d->n_local + d->n_halo; }
 const bis_mat *bis_dist_matrix(const bis_dist *d) { return d->A; }

@@ -158,3 +158,73 @@ def test_nongrid_ilu0_at_size_vs_oracle(ctx, oracle, order, persistent):
     assert np.array_equal(x.to_host(), oracle.sptrsv(U_dev, ud, to, backward=True))
     for m in (fLs, fUs, dA):
         m.free()
+
+
+def _random_chain_triangle(rng, n, band, p_link, max_extra, sort_cols, long_rows):
+    """strictly lower triangle: row r takes r - 1 with probability p_link plus a random number of earlier columns inside a band;
+    some rows are empty, some (long_rows) have more than 64 entries; columns ascending or shuffled"""
+    rp, cols = [0], []
+    for r in range(n):
+        c = set()
+        if r > 0 and rng.random() < p_link:
+            c.add(r - 1)
+        k = int(rng.integers(0, max_extra + 1))
+        if long_rows and r > 200 and rng.random() < 0.02:
+            k = int(rng.integers(65, 150))
+        lo = max(0, r - band)
+        if r > lo and k:
+            c.update(int(v) for v in rng.integers(lo, r, size=min(k, r - lo)))
+        if rng.random() < 0.03:
+            c = set()
+        c = np.array(sorted(c), dtype=np.int32)
+        if not sort_cols:
+            rng.shuffle(c)
+        cols.append(c)
+        rp.append(rp[-1] + len(c))
+    col = np.concatenate(cols) if rp[-1] else np.zeros(0, np.int32)
+    return np.array(rp, dtype=np.int64), col.astype(np.int32)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_chained_sweep_randomised_bit_exact(ctx, oracle, capfd, monkeypatch, seed):
+    """The chained sweep on random chain-rich triangles: empty rows, rows of more than 64 entries (several LDS slots per row),
+    unsorted columns (the chain-internal operand anywhere in the row), chains cut at 128 rows, 64-bit row pointers -- forward on
+    the triangle, backward on its mirror image, x aliasing b, twice on the same plan; bit-exact against the oracle, and the plan
+    must actually have been the chained one."""
+    from oracle.pyoracle import CRS
+    monkeypatch.setenv("BIS_TRSV_CHAIN_STATS", "1")
+    rng = np.random.default_rng(100 + seed)
+    n = 12000 + 777 * seed
+    rp, col = _random_chain_triangle(rng, n, band=[50, 3000, 400, n][seed % 4], p_link=[0.95, 0.8, 0.99, 0.6][seed % 4],
+                                     max_extra=[3, 40, 12, 6][seed % 4], sort_cols=seed % 3 != 1, long_rows=seed % 2 == 0)
+    val = rng.uniform(-1, 1, rp[-1]) / 8.0
+    D = rng.uniform(1.0, 2.0, n)
+    b = rng.uniform(-1, 1, n)
+    L = CRS(n, rp, col, val)
+    # the mirror image: row n-1-r, columns n-1-c (strictly upper, the backward sweep walks it in the same dependency order)
+    lens = np.diff(rp)[::-1]
+    rpu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in range(n - 1, -1, -1)]) if rp[-1] else np.zeros(0, np.int64)
+    U = CRS(n, rpu, (n - 1 - col[idx]).astype(np.int32), val[idx])
+    ctx.set_option("trsv_chain", 1)
+    ctx.set_option("force_rp64", 1 if seed % 4 == 3 else -1)
+    try:
+        dL, dU = ctx.matrix(L), ctx.matrix(U)
+        dD, db, x = ctx.upload(D), ctx.upload(b), ctx.alloc(n)
+        fw = oracle.sptrsv(L, D, b)
+        bw = oracle.sptrsv(U, D[::-1].copy(), b, backward=True)
+        dDr = ctx.upload(D[::-1].copy())
+        for _ in range(2):
+            ctx.sptrsv(dL, x, dD, db)
+            assert np.array_equal(x.to_host(), fw)
+            ctx.bsptrsv(dU, x, dDr, db)
+            assert np.array_equal(x.to_host(), bw)
+        ctx.copy_vector(x, db)
+        ctx.sptrsv(dL, x, dD, x)
+        assert np.array_equal(x.to_host(), fw)
+        err = capfd.readouterr().err
+        assert err.count("chained sptrsv plan") >= 2 and "NOT used" not in err and "too short" not in err, err
+    finally:
+        ctx.set_option("trsv_chain", -1)
+        ctx.set_option("force_rp64", -1)
+    dL.free(); dU.free()
