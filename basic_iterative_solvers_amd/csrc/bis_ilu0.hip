@@ -238,13 +238,33 @@ __global__ __launch_bounds__(256, 4) void ilu0_persistent_kernel(const RP *__res
         for (int q = lane; q < len; q += 64) { lcol[q] = wcol[s + q]; lval[q] = wval[s + q]; } // (the row's own entries: nobody else writes them)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        // An elimination is two dependent trips to memory -- (flag, where U's row k lies), then (pivot, the row's entries) -- and a row has
+        // ~35 of them.  What does not depend on row k being finished (its flag's current value, ustart[k], rp[k + 1]) is fetched for the NEXT
+        // elimination while this one runs; the pivot and the entries are loaded together once the flag has been seen (never before: loads of
+        // one wave may be served out of order, and a pivot read ahead of its flag could be the unfinished one).
+        int kn = len > 0 ? lcol[0] : i;
+        int fn = 1;
+        int64_t usn = 0, uen = 0;
+        if (kn < i) {
+            fn = __hip_atomic_load(&flag[kn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            usn = ustart[kn];
+            uen = (int64_t)rp[kn + 1];
+        }
         for (int p = 0; p < len; ++p) {
-            const int k = lcol[p]; // uniform
+            const int k = kn; // uniform
             if (k >= i) break;
+            int f = fn;
+            const int64_t us = usn, ue = uen;
+            kn = p + 1 < len ? lcol[p + 1] : i;
+            if (kn < i) {
+                fn = __hip_atomic_load(&flag[kn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                usn = ustart[kn];
+                uen = (int64_t)rp[kn + 1];
+            }
             // row k must be finished: its wave set the flag after its stores had drained
-            if (!aborted) {
+            if (!aborted && f == 0) {
                 unsigned spins = 0;
-                while (__hip_atomic_load(&flag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                while ((f = __hip_atomic_load(&flag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
                     if (++spins > kIluSpin || ((spins & 1023u) == 0u && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
                         aborted = true; // bounded: the factors are wrong from here on, the context's fault word says so
                         if (lane == 0) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -253,16 +273,20 @@ __global__ __launch_bounds__(256, 4) void ilu0_persistent_kernel(const RP *__res
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+            // pivot and the first 64 entries of U's row k in one trip
+            const int64_t q0 = us + lane;
+            const bool act0 = q0 < ue;
             const double pivot = __longlong_as_double((long long)__hip_atomic_load(&ud[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int j0 = wcol[act0 ? q0 : us];
+            const double u0 = __longlong_as_double((long long)__hip_atomic_load(&wv[act0 ? q0 : us], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (fabs(pivot) < 1e-16) continue;
             const double factor = lval[p] / pivot; // every lane computes the same value
-            const int64_t us = ustart[k], ue = (int64_t)rp[k + 1];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all lanes have read lval[p] before it is overwritten
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) lval[p] = factor;
-            for (int64_t q = us + lane; q < ue; q += 64) {
-                const int j = wcol[q];
-                const double u = __longlong_as_double((long long)__hip_atomic_load(&wv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            for (int64_t q = q0; q < ue; q += 64) {
+                const int j = q == q0 ? j0 : wcol[q];
+                const double u = q == q0 ? u0 : __longlong_as_double((long long)__hip_atomic_load(&wv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 int lo = p + 1, hi = len; // j > k: search the rest of row i
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
