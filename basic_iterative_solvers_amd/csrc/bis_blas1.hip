@@ -257,6 +257,7 @@ bis_options &bis_opts() {
         if (const char *e = getenv("BIS_SPMV_SELLWIN_ROWS")) v.spmv_sellwin_rows = atoi(e);
         if (const char *e = getenv("BIS_SPMV_SELLWIN_JOINT")) v.spmv_sellwin_joint = atoi(e);
         if (const char *e = getenv("BIS_SPMV_SELLWIN_PAIRS")) v.spmv_sellwin_pairs = atoi(e);
+        if (const char *e = getenv("BIS_SPMV_SELLWIN_MASKS")) v.spmv_sellwin_masks = atoi(e);
         if (const char *e = getenv("BIS_GRID_AUTODETECT")) v.grid_autodetect = atoi(e);
         if (const char *e = getenv("BIS_TUNE_PLACEMENT")) v.tune_placement = atoi(e);
         if (const char *e = getenv("BIS_CG_GRAPH")) v.cg_graph = atoi(e);
@@ -300,6 +301,7 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "spmv_sellwin_rows")) o.spmv_sellwin_rows = value;
     else if (!strcmp(name, "spmv_sellwin_joint")) o.spmv_sellwin_joint = value;
     else if (!strcmp(name, "spmv_sellwin_pairs")) o.spmv_sellwin_pairs = value;
+    else if (!strcmp(name, "spmv_sellwin_masks")) o.spmv_sellwin_masks = value;
     else if (!strcmp(name, "grid_autodetect")) o.grid_autodetect = value;
     else if (!strcmp(name, "tune_placement")) o.tune_placement = value;
     else if (!strcmp(name, "cg_graph")) o.cg_graph = value;

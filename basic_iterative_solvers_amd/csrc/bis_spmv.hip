@@ -1389,7 +1389,7 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
         if (A->rm_state == 1) f = A->vd_diag ? 3 : 2;
     }
     if (!f && a.vcode && !a.vd_rm_only && spmv_variant(a) == 20 && a.pk_mode == 1) f = 1;
-    if (col_bytes) *col_bytes = (f >= 4 && bis_spmv_sellwin_format(A) == 3) ? 1 : ((f >= 2 || a.pk_mode) ? 2 : 4); // 1: one byte per non-zero, the index of its (column - row, value) pair
+    if (col_bytes) *col_bytes = (f >= 4 && bis_spmv_sellwin_format(A) == 4) ? 0 : (f >= 4 && bis_spmv_sellwin_format(A) == 3) ? 1 : ((f >= 2 || a.pk_mode) ? 2 : 4); // 1: one byte per non-zero, the index of its (column - row, value) pair; 0: a 32-bit mask of pairs per ROW
     if (val_bytes) *val_bytes = f ? (f >= 4 && bis_spmv_sellwin_format(A) >= 2 ? 0 : 1) : 8; // 0: the value index shares the column code
     if (n_dict) *n_dict = f ? A->vd_n : 0;
     if (form) *form = f;

@@ -51,10 +51,11 @@ struct bis_sellwin {
     int fmt = 0;                     // 0: 12-byte chunks, value byte = table index; 1: value byte = 8 * index (<= 32 entries);
                                      // 2: 8-byte chunks, 16-bit codes slot : 13 | index : 3 (<= 8 entries);
                                      // 3: 4-byte chunks, one byte per non-zero = index of its (column - row, value) pair
+                                     // 4: no chunks: codes[row] = 32-bit mask of the row's pairs (see spmv_sellmask_kernel)
     int uniform_chunks = 0;          // > 0: every slice has this many chunks (short slices padded up when that costs < 3 % of the stream)
     int n_pairs = 0, pair_stride = 0, diag_pair = -1; // fmt 3: pairs of the matrix, int16 words per block in blk_base, the per-row-diagonal pair
     int16_t *blk_base = nullptr;     // fmt 3: [n_blocks * pair_stride] window slot of pair e's column for the block's first row
-    unsigned long long *pair_key = nullptr; // fmt 3: [256] the pairs, ascending ((uint32)(column - row) << 8 | value code)
+    unsigned long long *pair_key = nullptr; // fmt 3 / 4: [256] the pairs, ascending (sw_pair_key: column - row, then value code)
     int R = 1;                       // rows per lane: a block is 256 R rows
     bool diag = false;               // one value code stands for the row's own diagonal value (vdiag)
     int pad_idx = 0, diag_idx = 0;
@@ -71,6 +72,12 @@ constexpr int kSwDefaultR = 2;
 constexpr int kSwMaxPairs = 253; // fmt 3: pairs of a matrix at most (the padding takes the next index)
 // ... and with the tables in front of it the workgroup stays within 64 KiB of LDS
 inline int sw_gran_cap(int R) { return std::min(kSwMaxGran, (65536 - (4096 + 4096 * R) - 16) / 64); } // (the largest table area: fmt 3 with per-row diagonals)
+
+// a (column - row, value code) pair as one key: ascending keys = ascending (signed) offsets, so a row with ascending columns runs
+// through the sorted list front to back
+__device__ __forceinline__ unsigned long long sw_pair_key(int32_t offset, unsigned vcode) {
+    return ((unsigned long long)((unsigned)offset ^ 0x80000000u) << 8) | vcode;
+}
 
 __device__ __forceinline__ int sw_wave_max(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(64) void sw_pairs_kernel(const RP *__restrict__ row
             bool found = true;
             unsigned long long v = 0;
             if (k < k1) {
-                v = ((unsigned long long)(unsigned)(col[k] - (int32_t)(r + row0)) << 8) | vcode[k - vd_base];
+                v = sw_pair_key(col[k] - (int32_t)(r + row0), vcode[k - vd_base]);
                 found = false;
                 ++k;
             }
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256) void sw_fill_pairs_kernel(const RP *__restrict
                 unsigned e = (unsigned)n_pairs; // padding
                 if (j < len) {
                     const int ci = col[rs + j];
-                    const unsigned long long key = ((unsigned long long)(unsigned)(ci - (int32_t)(r + row0)) << 8) | vcode[rs + j - vd_base];
+                    const unsigned long long key = sw_pair_key(ci - (int32_t)(r + row0), vcode[rs + j - vd_base]);
                     int lo = 0, hi = n_pairs - 1;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
@@ -390,6 +397,77 @@ __global__ __launch_bounds__(256) void sw_fill_pairs_kernel(const RP *__restrict
     if (bad) atomicExch(&status[2], 1);
     __syncthreads();
     if (tid < pair_stride) blk_base[(size_t)b * pair_stride + tid] = base[tid] == INT32_MIN ? (int16_t)0 : (int16_t)base[tid];
+}
+
+// fmt 4: 32 bits per row -- bit e set: the row has pair e -- and the block's bases as in fmt 3.  Applies where the matrix has at
+// most 32 pairs and every row's entries run through the (ascending) pair list in ascending order, which a row with ascending
+// columns does: then "for e ascending: if bit e: acc += value(e) * x(e)" IS the row's CRS-ordered sum.  status[2] otherwise.
+// The bits are stored TRANSPOSED per 64-row slice: masks[slice * 32 + e] = the 64 rows' bit e, which is the execution mask of
+// pair e's step as the hardware wants it.
+template <typename RP>
+__global__ __launch_bounds__(256) void sw_fill_masks_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                            const uint8_t *__restrict__ vcode, int64_t vd_base, int64_t n_rows, int64_t row0,
+                                                            int R, const int32_t *__restrict__ hdr, unsigned long long *__restrict__ masks,
+                                                            const unsigned long long *__restrict__ pair_key, int n_pairs, int pair_stride,
+                                                            int16_t *__restrict__ blk_base, int *status) {
+    __shared__ int g0s[kSwRuns], rk[kSwRuns];
+    __shared__ int nr_s;
+    __shared__ unsigned long long keys[32];
+    __shared__ int base[32];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 32) {
+        keys[tid] = pair_key[tid];
+        base[tid] = INT32_MIN;
+    }
+    if (tid < kSwRuns) {
+        g0s[tid] = hdr[(size_t)b * 64 + tid];
+        const int w2 = hdr[(size_t)b * 64 + 32 + tid];
+        rk[tid] = w2 & 0xffff;
+        const unsigned long long m = __ballot((w2 >> 16) != 0);
+        if (tid == 0) nr_s = __popcll(m);
+    }
+    __syncthreads();
+    const int nr = nr_s;
+    bool bad = false;
+    for (int rr = 0; rr < R; ++rr) {
+        const int64_t slice = ((int64_t)b * 4 + wv) * R + rr;
+        const int64_t r = slice * 64 + lane;
+        const int r_in_block = (wv * R + rr) * 64 + lane;
+        uint32_t mask = 0;
+        if (r < n_rows) {
+            const int64_t rs = (int64_t)row_ptr[r], re = (int64_t)row_ptr[r + 1];
+            int prev = -1;
+            for (int64_t k = rs; k < re; ++k) {
+                const int ci = col[k];
+                const unsigned long long key = sw_pair_key(ci - (int32_t)(r + row0), vcode[k - vd_base]);
+                int lo = 0, hi = n_pairs - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                bad |= lo <= prev; // not in the list's order (or the same pair twice): the mask cannot say it
+                prev = lo;
+                mask |= 1u << lo;
+                const int g = ci >> 3;
+                int rl = 0, rh = nr - 1;
+                while (rl < rh) {
+                    const int mid = (rl + rh + 1) >> 1;
+                    if (g0s[mid] <= g) rl = mid; else rh = mid - 1;
+                }
+                const int delta = 2 + (rk[rl] + (g - g0s[rl])) * 8 + (ci & 7) - r_in_block;
+                const int old = atomicCAS(&base[lo], INT32_MIN, delta);
+                bad |= old != INT32_MIN && old != delta;
+            }
+        }
+        for (int e = 0; e < 32; ++e) {
+            const unsigned long long m = __ballot((mask >> e) & 1u);
+            if (lane == e) masks[(size_t)slice * 32 + e] = m;
+        }
+    }
+    if (bad) atomicExch(&status[2], 1);
+    __syncthreads();
+    // (fmt 4 keeps the bases as LDS byte offsets of 32 bits -- scalar loads have no 16-bit form --, 32 per block in the space of 64 int16)
+    if (tid < 32) reinterpret_cast<int32_t *>(blk_base)[(size_t)b * 32 + tid] = base[tid] == INT32_MIN ? 0 : 8 * base[tid];
 }
 
 template <int FMT> struct sw_chunk { uint32_t a, b, c; };
@@ -638,6 +716,212 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     if (dbg && tid == 0) { dbg[(size_t)b * 4 + 3] = (long long)__builtin_readcyclecounter() - t_start; dbg[(size_t)b * 4] = t_start; }
 }
 
+// fmt 4: y = A x from 32 bits per row.  The (at most 32) pairs of the matrix are the same for every row; lane e of each wave holds
+// pair e's value and the LDS address of its column for the block's first row, and -- per 64-row slice -- the 64-bit word that says
+// which of the slice's rows have the pair.  A step per pair moves these into scalar registers; the word becomes the execution mask
+// under which the rows that have the pair read their x entry from the window and add value * x -- in pair order, which is the rows'
+// CRS order.  Per non-zero: nothing streamed (4 bytes per ROW), ONE LDS read of 8 bytes, a multiply and an add; the byte codes of
+// fmt 3 cost two dependent LDS reads, 24 bytes of LDS traffic per non-zero -- at HPCG-256 75 % of that kernel's time on the LDS
+// pipe alone -- and some ten vector instructions.  Four pairs a step: four reads in flight, then four multiply-adds, each under
+// its rows' mask (hand-written: the compiler turns "if (bit) acc += v * x" into a branch and a full LDS wait per pair and row).
+// NP > 0: the number of pairs, known at compile time.  SMEM: the masks come through scalar loads instead of a vector load and
+// v_readlane.  LDS: 16 spare bytes, then the window.
+// One step: pairs q = 0..3 for the wave's R slices.  exec is all ones on entry -- no divergent control flow around the calls -- and
+// on exit; lanes outside a mask neither read nor add.  All 4 R reads are issued before the first is waited for.
+#define SM_RD(r, q, off) "s_mov_b64 exec, %[m" #r #q "]\n\tds_read_b64 %[x" #r #q "], %[a" #q "] offset:" #off "\n\t"
+#define SM_RD_ROW(r, off) SM_RD(r, 0, off) SM_RD(r, 1, off) SM_RD(r, 2, off) SM_RD(r, 3, off)
+#define SM_MA(r, q, vn) "s_mov_b64 exec, %[m" #r #q "]\n\tv_mul_f64 %[x" #r #q "], %[" vn "], %[x" #r #q "]\n\tv_add_f64 %[acc" #r "], %[acc" #r "], %[x" #r #q "]\n\t"
+#define SM_MA_ROW_S(r) SM_MA(r, 0, "v0") SM_MA(r, 1, "v1") SM_MA(r, 2, "v2") SM_MA(r, 3, "v3")
+#define SM_MA_ROW_V(r) SM_MA(r, 0, "v" #r "0") SM_MA(r, 1, "v" #r "1") SM_MA(r, 2, "v" #r "2") SM_MA(r, 3, "v" #r "3")
+#define SM_ADDR "v_add_u32 %[a0], %[xo0], %[roff]\n\tv_add_u32 %[a1], %[xo1], %[roff]\n\tv_add_u32 %[a2], %[xo2], %[roff]\n\tv_add_u32 %[a3], %[xo3], %[roff]\n\t"
+#define SM_WAIT "s_waitcnt lgkmcnt(0)\n\t"
+#define SM_END "s_mov_b64 exec, -1"
+#define SM_OUT_ROW(r) [acc##r] "+v"(acc[r]), [x##r##0] "=&v"(x[r][0]), [x##r##1] "=&v"(x[r][1]), [x##r##2] "=&v"(x[r][2]), [x##r##3] "=&v"(x[r][3])
+#define SM_OUT_A [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [a3] "=&v"(a[3])
+#define SM_IN_ROW(r) [m##r##0] "s"(m[r][0]), [m##r##1] "s"(m[r][1]), [m##r##2] "s"(m[r][2]), [m##r##3] "s"(m[r][3])
+#define SM_IN_A [roff] "v"(roff), [xo0] "s"(xo[0]), [xo1] "s"(xo[1]), [xo2] "s"(xo[2]), [xo3] "s"(xo[3])
+#define SM_IN_VS [v0] "s"(sv[0]), [v1] "s"(sv[1]), [v2] "s"(sv[2]), [v3] "s"(sv[3])
+#define SM_IN_VV(r) [v##r##0] "v"(vv[r][0]), [v##r##1] "v"(vv[r][1]), [v##r##2] "v"(vv[r][2]), [v##r##3] "v"(vv[r][3])
+// the table's values as multipliers (scalar registers)
+template <int R>
+__device__ __forceinline__ void sm_step(double (&acc)[R], unsigned roff, const unsigned (&xo)[4], const unsigned long long (&m)[R][4], const double (&sv)[4]) {
+    unsigned a[4];
+    double x[R][4];
+    if constexpr (R == 1)
+        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_WAIT SM_MA_ROW_S(0) SM_END : SM_OUT_ROW(0), SM_OUT_A : SM_IN_A, SM_IN_ROW(0), SM_IN_VS);
+    else if constexpr (R == 2)
+        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_WAIT SM_MA_ROW_S(0) SM_MA_ROW_S(1) SM_END
+                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_A : SM_IN_A, SM_IN_ROW(0), SM_IN_ROW(1), SM_IN_VS);
+    else
+        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_RD_ROW(2, 1024) SM_RD_ROW(3, 1536) SM_WAIT SM_MA_ROW_S(0) SM_MA_ROW_S(1)
+                     SM_MA_ROW_S(2) SM_MA_ROW_S(3) SM_END
+                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_ROW(2), SM_OUT_ROW(3), SM_OUT_A
+                     : SM_IN_A, SM_IN_ROW(0), SM_IN_ROW(1), SM_IN_ROW(2), SM_IN_ROW(3), SM_IN_VS);
+}
+// a multiplier per row and pair (vector registers): the per-row diagonal values
+template <int R>
+__device__ __forceinline__ void sm_step_v(double (&acc)[R], unsigned roff, const unsigned (&xo)[4], const unsigned long long (&m)[R][4], const double (&vv)[R][4]) {
+    unsigned a[4];
+    double x[R][4];
+    if constexpr (R == 1)
+        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_WAIT SM_MA_ROW_V(0) SM_END : SM_OUT_ROW(0), SM_OUT_A : SM_IN_A, SM_IN_ROW(0), SM_IN_VV(0));
+    else if constexpr (R == 2)
+        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_WAIT SM_MA_ROW_V(0) SM_MA_ROW_V(1) SM_END
+                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_A : SM_IN_A, SM_IN_ROW(0), SM_IN_ROW(1), SM_IN_VV(0), SM_IN_VV(1));
+    else
+        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_RD_ROW(2, 1024) SM_RD_ROW(3, 1536) SM_WAIT SM_MA_ROW_V(0) SM_MA_ROW_V(1)
+                     SM_MA_ROW_V(2) SM_MA_ROW_V(3) SM_END
+                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_ROW(2), SM_OUT_ROW(3), SM_OUT_A
+                     : SM_IN_A, SM_IN_ROW(0), SM_IN_ROW(1), SM_IN_ROW(2), SM_IN_ROW(3), SM_IN_VV(0), SM_IN_VV(1), SM_IN_VV(2), SM_IN_VV(3));
+}
+
+template <int MODE, bool DIAG, int R, int NP, bool SMEM>
+__global__ __launch_bounds__(256) void spmv_sellmask_kernel(
+    const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
+    double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const unsigned long long *__restrict__ masks,
+    const double *__restrict__ dict_g, const double *__restrict__ vdiag, int x_flags, const int16_t *__restrict__ blk_base, int pair_stride,
+    int n_pairs_arg, int diag_pair, const int32_t *__restrict__ own_rank) {
+    const bool x_al16 = (x_flags & 1) != 0, nt_codes = (x_flags & 2) != 0;
+    if (stop && stop[1]) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int b = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
+                                : (remap_arg < -1 ? xcd_group_remap(blockIdx.x, -remap_arg) : (int)blockIdx.x);
+    if (b >= n_blocks) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_pairs = NP > 0 ? NP : n_pairs_arg;
+    const int hw = hdr[(size_t)b * 64 + lane];
+    const int64_t slice0 = ((int64_t)b * 4 + wv) * R;
+    // lane e (+ 32 for the wave's second slice): which rows of the slice have pair e
+    constexpr int TV = (R + 1) / 2;
+    unsigned long long tv[TV];
+#pragma unroll
+    for (int h = 0; h < TV; ++h) {
+        tv[h] = 0ull;
+        const unsigned long long *mp = &masks[(slice0 + 2 * h) * 32 + lane];
+        if (!SMEM && lane < 32 * min(R - 2 * h, 2)) tv[h] = nt_codes ? __builtin_nontemporal_load(mp) : *mp;
+    }
+    // pair `lane`: its value and where its column for the block's first row lies in LDS
+    double pv = 0.0;
+    int pxo = 0;
+    const int32_t *__restrict__ bb32 = reinterpret_cast<const int32_t *>(blk_base) + (size_t)b * 32;
+    if (!SMEM && lane < n_pairs) {
+        pv = dict_g[lane];
+        pxo = bb32[lane];
+    }
+    double wr[R], dval[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (slice0 + r) * 64 + lane;
+        wr[r] = 0.0;
+        if (MODE == 1 && !own_rank && row < n_rows) wr[r] = w[row];
+        if (DIAG) dval[r] = row < n_rows ? vdiag[row] : 0.0;
+    }
+    int own = -1;
+    if (MODE == 1 && own_rank) {
+        own = own_rank[b];
+        if (own < 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int64_t row = (slice0 + r) * 64 + lane; if (row < n_rows) wr[r] = w[row]; }
+        }
+    }
+    { // the window: as in spmv_sellwin_kernel
+        const int n_runs = __popcll(__ballot(lane >= 32 && (hw >> 16) != 0));
+        unsigned char *win = lds + 16;
+        for (int k = 0; k < n_runs; ++k) {
+            const int g0 = __builtin_amdgcn_readlane(hw, k);
+            const int w2 = __builtin_amdgcn_readlane(hw, 32 + k);
+            const int rank = w2 & 0xffff, n_pieces = (w2 >> 16) * 4;
+            const int j = (wv + k) & 3;
+            const int p = j * 64 + lane;
+            const int64_t c = (int64_t)g0 * 8 + 2 * p;
+            unsigned char *dst = win + (size_t)rank * 64 + (size_t)j * 1024;
+            if (p < n_pieces) {
+                if (x_al16 && c + 1 < n_cols) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + c),
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                } else {
+                    double2 v;
+                    v.x = c < n_cols ? x[c] : 0.0;
+                    v.y = c + 1 < n_cols ? x[c + 1] : 0.0;
+                    *reinterpret_cast<double2 *>(dst + lane * 16) = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    const unsigned row_off0 = (unsigned)((wv * R * 64 + lane) * 8); // (the wave's slice r: + 512 r)
+    const unsigned pv_lo = (unsigned)(unsigned long long)__double_as_longlong(pv), pv_hi = (unsigned)((unsigned long long)__double_as_longlong(pv) >> 32);
+    // four pairs a step, the next step's scalars loaded (SMEM) before this step's LDS reads are waited for
+    struct Step { unsigned xo[4]; double sv[4]; unsigned long long m[R][4]; };
+    auto fetch = [&](int e0, Step &g) { // pairs e0 .. e0 + 3 (those past the last have empty masks)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = min(e0 + q, 31);
+            if (SMEM) {
+                g.xo[q] = (unsigned)bb32[e];
+                g.sv[q] = dict_g[e];
+            } else {
+                g.xo[q] = (unsigned)__builtin_amdgcn_readlane(pxo, e);
+                g.sv[q] = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)pv_hi, e) << 32) |
+                                                           (unsigned)__builtin_amdgcn_readlane((int)pv_lo, e)));
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (e0 + q >= 32) g.m[r][q] = 0ull;
+                else if (SMEM) g.m[r][q] = masks[(slice0 + r) * 32 + e];
+                else g.m[r][q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(tv[r / 2] >> 32), (r & 1) * 32 + e) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tv[r / 2], (r & 1) * 32 + e);
+            }
+        }
+    };
+    auto apply = [&](int e0, const Step &g) {
+        if constexpr (DIAG) { // the diagonal pair's value is the row's own
+            double vv[R][4];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[r][q] = e0 + q == diag_pair ? dval[r] : g.sv[q];
+            sm_step_v<R>(acc, row_off0, g.xo, g.m, vv);
+        } else {
+            sm_step<R>(acc, row_off0, g.xo, g.m, g.sv);
+        }
+    };
+    Step cur, nxt;
+    fetch(0, cur);
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int e0 = 0; e0 < NP; e0 += 4) {
+            // (this step's scalars have arrived -- the step before waited for everything -- but the compiler does not see waits inside
+            // the hand-written steps: told here, it does not put its own wait BEHIND the next fetch)
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+            if (e0 + 4 < NP) fetch(e0 + 4, nxt);
+            apply(e0, cur);
+            cur = nxt;
+        }
+    } else {
+        for (int e0 = 0; e0 < n_pairs; e0 += 4) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            fetch(min(e0 + 4, 28), nxt); // (past the last pair: fetched, not used)
+            apply(e0, cur);
+            cur = nxt;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (slice0 + r) * 64 + lane;
+        if (row < n_rows) y[row] = acc[r];
+        if (MODE == 1) {
+            if (own >= 0) wr[r] = *reinterpret_cast<const double *>(lds + 16 + ((size_t)own * 8 + (wv * R + r) * 64 + lane) * 8);
+            const double t = wave_sum(row < n_rows ? acc[r] * wr[r] : 0.0);
+            if (lane == 0) partials[slice0 + r] = t;
+        }
+    }
+}
+
 // (Measured and removed: a "chained" variant of the fmt 3 kernel in which one workgroup walks 2 / 4 / 8 consecutive blocks and
 // loads the next block's header, codes and pair bases while the current block computes, so that only a workgroup's first
 // block pays for the header trip: HPCG-256 in the CG loop 0.218 / 0.224 / 0.235 ms against 0.205 ms with one block per
@@ -724,46 +1008,57 @@ static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, in
     }
     vals[n_pairs] = table[pad_idx]; // the padding entry: 1.0
     const int stride = (n_pairs + 63) / 64 * 64;
-    const int64_t total = sw->total_chunks;
     const int nb = sw->n_blocks;
-    int16_t *blk_base = nullptr;
-    unsigned long long *pair_key = nullptr;
-    uint32_t *codes = nullptr;
-    double *dict3 = nullptr;
-    hipError_t e = hipMalloc(&blk_base, sizeof(int16_t) * (size_t)stride * (size_t)nb);
-    if (e == hipSuccess) e = hipMalloc(&pair_key, sizeof keys);
-    if (e == hipSuccess) e = hipMalloc(&codes, sizeof(uint32_t) * 64 * (size_t)(total + 1));
-    if (e == hipSuccess) e = hipMalloc(&dict3, sizeof vals);
-    if (e == hipSuccess) e = hipMemcpyAsync(pair_key, keys, sizeof keys, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dict3, vals, sizeof vals, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(codes + (size_t)total * 64, 0, sizeof(uint32_t) * 64, ctx->stream);
-    if (e == hipSuccess) {
+    // fmt 4 (a mask per row) where the pairs fit 32 bits and the rows run through them in order, else fmt 3 (a byte per non-zero)
+    for (int attempt = (n_pairs <= 32 && bis_opts().spmv_sellwin_masks != 0) ? 0 : 1; attempt < 2; ++attempt) {
+        const bool masks = attempt == 0;
+        const int64_t total = sw->total_chunks;
+        const size_t code_words = masks ? (size_t)nb * 256 * (size_t)sw->R : 64 * (size_t)(total + 1);
+        int16_t *blk_base = nullptr;
+        unsigned long long *pair_key = nullptr;
+        uint32_t *codes = nullptr;
+        double *dict3 = nullptr;
+        hipError_t e = hipMalloc(&blk_base, sizeof(int16_t) * (size_t)stride * (size_t)nb);
+        if (e == hipSuccess) e = hipMalloc(&pair_key, sizeof keys);
+        if (e == hipSuccess) e = hipMalloc(&codes, sizeof(uint32_t) * code_words);
+        if (e == hipSuccess) e = hipMalloc(&dict3, sizeof vals);
+        if (e == hipSuccess) e = hipMemcpyAsync(pair_key, keys, sizeof keys, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dict3, vals, sizeof vals, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(status + 2, 0, sizeof(int), ctx->stream);
+        if (e == hipSuccess && !masks) e = hipMemsetAsync(codes + (size_t)total * 64, 0, sizeof(uint32_t) * 64, ctx->stream);
+        if (e == hipSuccess) {
 #define SW_FILLP(RP) hipLaunchKernelGGL((sw_fill_pairs_kernel<RP>), dim3(nb), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, A->view_row0, sw->R, sw->hdr, sw->slice_chunk0, codes, pair_key, n_pairs, stride, blk_base, status)
-        if (A->rp64) SW_FILLP(int64_t); else SW_FILLP(int32_t);
+#define SW_FILLM(RP) hipLaunchKernelGGL((sw_fill_masks_kernel<RP>), dim3(nb), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, A->view_row0, sw->R, sw->hdr, (unsigned long long *)codes, pair_key, n_pairs, stride, blk_base, status)
+            if (masks) { if (A->rp64) SW_FILLM(int64_t); else SW_FILLM(int32_t); }
+            else { if (A->rp64) SW_FILLP(int64_t); else SW_FILLP(int32_t); }
 #undef SW_FILLP
-        e = hipGetLastError();
+#undef SW_FILLM
+            e = hipGetLastError();
+        }
+        int bad = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, status + 2, sizeof bad, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // keys[], vals[], bad
+        if (e != hipSuccess || bad) {
+            hipFree(blk_base); hipFree(pair_key); hipFree(codes); hipFree(dict3);
+            if (e == hipSuccess && masks) continue; // the byte codes then
+            if (e == hipSuccess || e == hipErrorOutOfMemory) { (void)hipGetLastError(); return BIS_OK; } // another format
+            ctx->err = std::string("bis_spmv sellwin pairs: ") + hipGetErrorString(e);
+            bis_spmv_sellwin_drop(A);
+            A->sw_state = -1;
+            return BIS_ERR_HIP;
+        }
+        hipFree(sw->dict);
+        sw->dict = dict3;
+        sw->codes = codes;
+        sw->blk_base = blk_base;
+        sw->pair_key = pair_key;
+        sw->fmt = masks ? 4 : 3;
+        sw->n_pairs = n_pairs;
+        sw->pair_stride = stride;
+        sw->diag_pair = diag_pair;
+        A->sw_state = 1;
+        return BIS_OK;
     }
-    int bad = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&bad, status + 2, sizeof bad, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // keys[], vals[], bad
-    if (e != hipSuccess || bad) {
-        hipFree(blk_base); hipFree(pair_key); hipFree(codes); hipFree(dict3);
-        if (e == hipSuccess || e == hipErrorOutOfMemory) { (void)hipGetLastError(); return BIS_OK; } // another format
-        ctx->err = std::string("bis_spmv sellwin pairs: ") + hipGetErrorString(e);
-        bis_spmv_sellwin_drop(A);
-        A->sw_state = -1;
-        return BIS_ERR_HIP;
-    }
-    hipFree(sw->dict);
-    sw->dict = dict3;
-    sw->codes = codes;
-    sw->blk_base = blk_base;
-    sw->pair_key = pair_key;
-    sw->fmt = 3;
-    sw->n_pairs = n_pairs;
-    sw->pair_stride = stride;
-    sw->diag_pair = diag_pair;
-    A->sw_state = 1;
     return BIS_OK;
 }
 
@@ -774,7 +1069,7 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     if (!sw_enabled() || A->vd_state != 1 || A->n_rows == 0 || A->nnz == 0 || A->n_cols >= ((int64_t)1 << 31) - 16) return BIS_OK;
     int R = kSwDefaultR;
     while (R > 1 && A->n_rows < (int64_t)kSwRows * R * 1024) R >>= 1; // small matrices: more, smaller blocks
-    if (bis_opts().spmv_sellwin_rows > 0) R = bis_opts().spmv_sellwin_rows >= 2 ? 2 : 1;
+    if (bis_opts().spmv_sellwin_rows > 0) R = bis_opts().spmv_sellwin_rows >= 4 ? 4 : (bis_opts().spmv_sellwin_rows >= 2 ? 2 : 1);
     const int64_t nb64 = (A->n_rows + (int64_t)kSwRows * R - 1) / ((int64_t)kSwRows * R);
     if (nb64 > (int64_t)1 << 26) return BIS_OK;
     const int nb = (int)nb64;
@@ -855,8 +1150,14 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     // block's window in step with the rows
     if (bis_opts().spmv_sellwin_pairs != 0) {
         if (bis_status st = sw_try_pairs(ctx, A, table, pad_idx)) return st;
+        if (A->sw && sw->R == 4 && !(A->sw_state == 1 && sw->fmt == 4)) { // (blocks of 1024 rows exist for the row-mask form only)
+            bis_spmv_sellwin_drop(A);
+            A->sw_state = -1;
+            return BIS_OK;
+        }
         if (A->sw_state == 1 || !A->sw) return BIS_OK;
     }
+    if (sw->R == 4) { bis_spmv_sellwin_drop(A); A->sw_state = -1; return BIS_OK; }
     const size_t cw = sw->fmt == 2 ? 128 : 192; // 32-bit words per chunk of 64 lanes
     SW_CHECK(hipMalloc(&sw->codes, sizeof(uint32_t) * cw * (size_t)(total + 1)));
     SW_CHECK(hipMemsetAsync(sw->codes + (size_t)total * cw, 0, sizeof(uint32_t) * cw, ctx->stream));
@@ -875,6 +1176,8 @@ int bis_spmv_sellwin_format(const bis_mat *A) { return A->sw_state == 1 ? A->sw-
 // bytes of the form's own arrays one launch reads: the code stream (with its padding), block headers, slice offsets, table
 int64_t bis_spmv_sellwin_bytes(const bis_mat *A) {
     if (A->sw_state != 1) return 0;
+    if (A->sw->fmt == 4) // a mask per row, the block headers and bases, the pairs' values
+        return 4 * (int64_t)A->sw->n_blocks * 256 * A->sw->R + (int64_t)A->sw->n_blocks * (256 + 2 * A->sw->pair_stride + 4) + 2048;
     const int64_t chunk_bytes = A->sw->fmt == 3 ? 256 : (A->sw->fmt == 2 ? 512 : 768);
     return A->sw->total_chunks * chunk_bytes + (int64_t)A->sw->n_blocks * (256 + 2 * A->sw->pair_stride) + 8 * (A->sw->n_slices + 1) + 2048;
 }
@@ -896,6 +1199,25 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
         dbg = dbg_buf;
     }
     const int32_t *own = (mode == 1 && w == x + A->view_row0 && x_al16) ? sw->own_rank : nullptr; // the fused dot's w is x itself (CG: p)
+    if (sw->fmt == 4) {
+#define SM_L3(MODE, DIAG, RR, NN)                                                                                          \
+    hipLaunchKernelGGL((spmv_sellmask_kernel<MODE, DIAG, RR, NN, false>), dim3(grid), dim3(256), win, ctx->stream, x, y, A->n_rows, A->n_cols, \
+                       sw->n_blocks, remap_arg, w, partials, stop, sw->hdr, (const unsigned long long *)sw->codes, sw->dict, A->vdiag, \
+                       x_al16 | (bis_opts().spmv_sellwin_nt != 0 ? 2 : 0), sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own)
+#define SM_L2(MODE, DIAG) do {                                                                                             \
+        if (sw->R == 4 && sw->n_pairs == 27) SM_L3(MODE, DIAG, 4, 27);                                                     \
+        else if (sw->R == 4) SM_L3(MODE, DIAG, 4, 0);                                                                      \
+        else if (sw->R == 2 && sw->n_pairs == 27) SM_L3(MODE, DIAG, 2, 27);                                                \
+        else if (sw->R == 2 && sw->n_pairs == 7) SM_L3(MODE, DIAG, 2, 7);                                                  \
+        else if (sw->R == 2) SM_L3(MODE, DIAG, 2, 0); else SM_L3(MODE, DIAG, 1, 0); } while (0)
+#define SM_L1(MODE) do { if (sw->diag) SM_L2(MODE, true); else SM_L2(MODE, false); } while (0)
+        if (mode == 1) SM_L1(1); else SM_L1(0);
+#undef SM_L1
+#undef SM_L2
+#undef SM_L3
+        BIS_HIP_CHECK(ctx, hipGetLastError());
+        return BIS_OK;
+    }
 #define SW_L4(MODE, DIAG, FMT, RR)                                                                                     \
     hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, FMT, RR>), dim3(grid), dim3(256), (FMT == 3 ? win_off3 : (size_t)(SwLayout<DIAG, FMT, RR>::kWinOff)) + win, \
                        ctx->stream, x, y, A->n_rows, A->n_cols, sw->n_blocks, remap_arg, w, partials, stop, sw->hdr,   \

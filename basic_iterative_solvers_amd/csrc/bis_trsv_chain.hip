@@ -447,12 +447,19 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                     // registers (p1..p3), older ones in the ring of the chain's results; the lanes that hold them write them into the slot.
                     // (Picking them inside the one-lane chain instead -- a compare and a few selects per entry -- made every entry cost 64 ns:
                     // a lone lane's instruction issue, not the fma's latency, then paces the chain.)
-                    if ((unsigned)(ev >> 32) == kInternalTag) {
+                    // (branch-free selects and one store under the tag: as nested ?: the compiler made it a chain of branches, 1.4x the cycles)
+                    {
+                        const bool tagged = (unsigned)(ev >> 32) == kInternalTag;
                         const int dist = (int)(unsigned)ev;
-                        const int orow = BACKWARD ? r + dist : r - dist;
-                        const unsigned long long w = dist == 1 ? p1 : dist == 2 ? p2 : dist == 3 ? p3
-                                                     : __hip_atomic_load(&L.res[orow & (kMaxChain - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_store(&S[lane].v, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        unsigned long long w = p3;
+                        w = dist == 2 ? p2 : w;
+                        w = dist == 1 ? p1 : w;
+                        if (__ballot(tagged && dist > 3)) {
+                            const int orow = BACKWARD ? r + dist : r - dist;
+                            const unsigned long long o = __hip_atomic_load(&L.res[orow & (kMaxChain - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            w = dist > 3 ? o : w;
+                        }
+                        if (tagged) __hip_atomic_store(&S[lane].v, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     asm volatile("" ::: "memory");
                     // acc = fma(a_i, x_i, acc) in CRS order -- the reference's chain exactly -- by ONE lane, from entry q0 on (the feeder has

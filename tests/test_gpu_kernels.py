@@ -1300,8 +1300,9 @@ def _banded_few_values(rng, n, n_values, offsets, max_len, ragged=4, empty_every
     return CRS(n, rp, col, val, n_cols=n_cols)
 
 
-@pytest.mark.parametrize("rp64,rows,joint,pairs", [(0, 1, -1, -1), (1, 2, -1, -1), (0, 2, -1, 0), (1, 1, -1, 0), (0, 2, 0, 0), (1, 1, 0, 0)])
-def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pairs):
+@pytest.mark.parametrize("rp64,rows,joint,pairs,masks", [(0, 1, -1, -1, -1), (1, 2, -1, -1, -1), (0, 2, -1, -1, 0), (1, 1, -1, -1, 0), (0, 2, -1, 0, -1),
+                                                         (1, 1, -1, 0, -1), (0, 2, 0, 0, -1), (1, 1, 0, 0, -1)])
+def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pairs, masks):
     """Forms 4 / 5 of the dictionary SpMV (bis_spmv_sell.hip): the block's x entries in an LDS window, the codes per
     64-row slice in lane order with neutral padding.  y is BIT-IDENTICAL to the kernel that streams the CRS values and
     within the kernel tolerance of the oracle (kernels.hpp:22-42): stencils, banded matrices with several column runs,
@@ -1310,7 +1311,8 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pair
     past the last column), an x that is only 8-byte aligned, 64-bit row pointers; blocks of 256 and of 512 rows
     (option spmv_sellwin_rows); the one-byte (column - row, value) pair codes of stencil matrices (at most 253 pairs,
     each running through every block's window in step with the rows; a pair with a gap in its run inside a block, or
-    too many pairs, takes the next format: spmv_sellwin_pairs 0 forces that), the 16-bit joint codes (tables of at most
+    too many pairs, takes the next format: spmv_sellwin_pairs 0 forces that), in their place 32 bits per ROW -- which of the matrix'
+    pairs the row has -- where the matrix has at most 32 pairs and the rows' columns ascend (spmv_sellwin_masks 0: never), the 16-bit joint codes (tables of at most
     8 entries) and the 12-byte chunks in their place (spmv_sellwin_joint 0); matrices that do not qualify (256 values: no free code for the padding; scattered
     columns; mostly-padding rows) keep the gather forms."""
     rng = np.random.default_rng(90 + rp64)
@@ -1318,6 +1320,7 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pair
     ctx.set_option("spmv_sellwin_rows", rows)
     ctx.set_option("spmv_sellwin_joint", joint)
     ctx.set_option("spmv_sellwin_pairs", pairs)
+    ctx.set_option("spmv_sellwin_masks", masks)
     offs_band = np.arange(-40, 41)
     offs_runs = np.concatenate([np.arange(-3, 4), np.arange(-3, 4) + 700, np.arange(-3, 4) - 700, np.arange(-3, 4) + 5000, np.arange(-3, 4) - 5000])
     neg0 = CRS(300, np.arange(0, 301 * 3, 3), np.repeat(np.arange(300), 3).astype(np.int32), np.tile([-0.0, 0.0, -0.0], 300))
@@ -1363,7 +1366,10 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pair
                         stencil = name.startswith(("hpcg", "anderson", "-0.0", "one row"))
                         few = A.nnz > 0 and len(np.unique(A.val.view(np.uint64))) <= 6 and want == 4
                         if stencil and pairs != 0:
-                            assert info[:2] == (1, 0), (name, info)
+                            if masks != 0 and name.startswith(("hpcg", "anderson")):
+                                assert info[:2] == (0, 0), (name, info)  # nothing per non-zero: 32 bits per row
+                            else:
+                                assert info[:2] in ((1, 0), (0, 0)) and (masks != 0 or info[0] == 1), (name, info)
                         elif (few and joint != 0) or (name.startswith("anderson") and joint != 0):
                             assert info[:2] == (2, 0), (name, info)
                         if name.startswith("gap"):
@@ -1393,10 +1399,11 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pair
         ctx.set_option("spmv_sellwin_rows", -1)
         ctx.set_option("spmv_sellwin_joint", -1)
         ctx.set_option("spmv_sellwin_pairs", -1)
+        ctx.set_option("spmv_sellwin_masks", -1)
 
 
-@pytest.mark.parametrize("rows", [1, 2])
-def test_spmv_sellwin_in_fused_cg(ctx, oracle, rows):
+@pytest.mark.parametrize("rows,masks", [(1, -1), (2, -1), (2, 0)])
+def test_spmv_sellwin_in_fused_cg(ctx, oracle, rows, masks):
     """The fused (Ap, p) epilogue of form 4 sums over the same 256-row blocks and waves as the lane-per-row gather
     form: the CG history is bit-identical to it, and within 1e-10 r0 of the oracle's (methods/cg.hpp:6-54);
     in-place scaling drops the form and the next SpMV rebuilds it from the new values."""
@@ -1405,6 +1412,7 @@ def test_spmv_sellwin_in_fused_cg(ctx, oracle, rows):
     n = A.n_rows
     hists = {}
     ctx.set_option("spmv_sellwin_rows", rows)
+    ctx.set_option("spmv_sellwin_masks", masks)
     try:
         for sw in (0, -1):
             ctx.set_option("spmv_sellwin", sw)
@@ -1436,6 +1444,7 @@ def test_spmv_sellwin_in_fused_cg(ctx, oracle, rows):
     finally:
         ctx.set_option("spmv_sellwin", -1)
         ctx.set_option("spmv_sellwin_rows", -1)
+        ctx.set_option("spmv_sellwin_masks", -1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 777, 4096, 100001, 1 << 20])
