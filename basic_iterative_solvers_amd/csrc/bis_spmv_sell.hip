@@ -402,12 +402,11 @@ __global__ __launch_bounds__(256) void sw_fill_pairs_kernel(const RP *__restrict
 // fmt 4: 32 bits per row -- bit e set: the row has pair e -- and the block's bases as in fmt 3.  Applies where the matrix has at
 // most 32 pairs and every row's entries run through the (ascending) pair list in ascending order, which a row with ascending
 // columns does: then "for e ascending: if bit e: acc += value(e) * x(e)" IS the row's CRS-ordered sum.  status[2] otherwise.
-// The bits are stored TRANSPOSED per 64-row slice: masks[slice * 32 + e] = the 64 rows' bit e, which is the execution mask of
-// pair e's step as the hardware wants it.
+// Pair e is bit 31 - e: the kernel shifts the word left a bit per pair and takes the carry.
 template <typename RP>
 __global__ __launch_bounds__(256) void sw_fill_masks_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col,
                                                             const uint8_t *__restrict__ vcode, int64_t vd_base, int64_t n_rows, int64_t row0,
-                                                            int R, const int32_t *__restrict__ hdr, unsigned long long *__restrict__ masks,
+                                                            int R, const int32_t *__restrict__ hdr, uint32_t *__restrict__ masks,
                                                             const unsigned long long *__restrict__ pair_key, int n_pairs, int pair_stride,
                                                             int16_t *__restrict__ blk_base, int *status) {
     __shared__ int g0s[kSwRuns], rk[kSwRuns];
@@ -459,10 +458,7 @@ __global__ __launch_bounds__(256) void sw_fill_masks_kernel(const RP *__restrict
                 bad |= old != INT32_MIN && old != delta;
             }
         }
-        for (int e = 0; e < 32; ++e) {
-            const unsigned long long m = __ballot((mask >> e) & 1u);
-            if (lane == e) masks[(size_t)slice * 32 + e] = m;
-        }
+        masks[(size_t)slice * 64 + lane] = __brev(mask);
     }
     if (bad) atomicExch(&status[2], 1);
     __syncthreads();
@@ -716,209 +712,179 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
     if (dbg && tid == 0) { dbg[(size_t)b * 4 + 3] = (long long)__builtin_readcyclecounter() - t_start; dbg[(size_t)b * 4] = t_start; }
 }
 
-// fmt 4: y = A x from 32 bits per row.  The (at most 32) pairs of the matrix are the same for every row; lane e of each wave holds
-// pair e's value and the LDS address of its column for the block's first row, and -- per 64-row slice -- the 64-bit word that says
-// which of the slice's rows have the pair.  A step per pair moves these into scalar registers; the word becomes the execution mask
-// under which the rows that have the pair read their x entry from the window and add value * x -- in pair order, which is the rows'
-// CRS order.  Per non-zero: nothing streamed (4 bytes per ROW), ONE LDS read of 8 bytes, a multiply and an add; the byte codes of
-// fmt 3 cost two dependent LDS reads, 24 bytes of LDS traffic per non-zero -- at HPCG-256 75 % of that kernel's time on the LDS
-// pipe alone -- and some ten vector instructions.  Four pairs a step: four reads in flight, then four multiply-adds, each under
-// its rows' mask (hand-written: the compiler turns "if (bit) acc += v * x" into a branch and a full LDS wait per pair and row).
-// NP > 0: the number of pairs, known at compile time.  SMEM: the masks come through scalar loads instead of a vector load and
-// v_readlane.  LDS: 16 spare bytes, then the window.
-// One step: pairs q = 0..3 for the wave's R slices.  exec is all ones on entry -- no divergent control flow around the calls -- and
-// on exit; lanes outside a mask neither read nor add.  All 4 R reads are issued before the first is waited for.
+// fmt 4: y = A x from 32 bits per row.  The (at most 32) pairs of the matrix are the same for every row; a wave-uniform step per
+// pair has the pair's value and the LDS address of its column for the block's first row in scalar registers, and the rows that
+// have the pair read their x entry from the window and add value * x -- in pair order, which is the rows' CRS order.  "The rows
+// that have the pair" is the hardware's execution mask: v_add_co_u32 mask, mask, mask shifts a row's word left and delivers the
+// bit that falls out -- the next pair's -- for all 64 rows as a scalar register pair, ONE vector instruction per row and pair.
+// Per non-zero: nothing streamed (4 bytes per ROW), ONE LDS read of 8 bytes, that add, a multiply and an add; the byte codes of
+// fmt 3 cost two dependent LDS reads (24 bytes of LDS traffic per non-zero: at HPCG-256 75 % of that kernel's time on the LDS
+// pipe alone) and some ten vector instructions.  Four pairs a step and all the wave's R slices at once: 4 R reads in flight,
+// then 4 R multiply-adds, each under its rows' mask -- hand-written: the compiler turns "if (bit) acc += v * x" into a branch and
+// a full LDS wait per pair and row.  exec is all ones on entry (no divergent control flow around the steps) and on exit.
+#define SM_BIT(r, q) "v_add_co_u32 %[mk" #r "], %[m" #r #q "], %[mk" #r "], %[mk" #r "]\n\t"
+#define SM_BIT_ROW(r) SM_BIT(r, 0) SM_BIT(r, 1) SM_BIT(r, 2) SM_BIT(r, 3)
 #define SM_RD(r, q, off) "s_mov_b64 exec, %[m" #r #q "]\n\tds_read_b64 %[x" #r #q "], %[a" #q "] offset:" #off "\n\t"
 #define SM_RD_ROW(r, off) SM_RD(r, 0, off) SM_RD(r, 1, off) SM_RD(r, 2, off) SM_RD(r, 3, off)
-#define SM_MA(r, q, vn) "s_mov_b64 exec, %[m" #r #q "]\n\tv_mul_f64 %[x" #r #q "], %[" vn "], %[x" #r #q "]\n\tv_add_f64 %[acc" #r "], %[acc" #r "], %[x" #r #q "]\n\t"
-#define SM_MA_ROW_S(r) SM_MA(r, 0, "v0") SM_MA(r, 1, "v1") SM_MA(r, 2, "v2") SM_MA(r, 3, "v3")
-#define SM_MA_ROW_V(r) SM_MA(r, 0, "v" #r "0") SM_MA(r, 1, "v" #r "1") SM_MA(r, 2, "v" #r "2") SM_MA(r, 3, "v" #r "3")
+#define SM_MA(r, q) "s_mov_b64 exec, %[m" #r #q "]\n\tv_mul_f64 %[x" #r #q "], %[v" #q "], %[x" #r #q "]\n\tv_add_f64 %[acc" #r "], %[acc" #r "], %[x" #r #q "]\n\t"
+#define SM_MA_ROW(r) SM_MA(r, 0) SM_MA(r, 1) SM_MA(r, 2) SM_MA(r, 3)
 #define SM_ADDR "v_add_u32 %[a0], %[xo0], %[roff]\n\tv_add_u32 %[a1], %[xo1], %[roff]\n\tv_add_u32 %[a2], %[xo2], %[roff]\n\tv_add_u32 %[a3], %[xo3], %[roff]\n\t"
 #define SM_WAIT "s_waitcnt lgkmcnt(0)\n\t"
 #define SM_END "s_mov_b64 exec, -1"
-#define SM_OUT_ROW(r) [acc##r] "+v"(acc[r]), [x##r##0] "=&v"(x[r][0]), [x##r##1] "=&v"(x[r][1]), [x##r##2] "=&v"(x[r][2]), [x##r##3] "=&v"(x[r][3])
+#define SM_OUT_ROW(r) [acc##r] "+v"(acc[r]), [mk##r] "+v"(mk[r]), [x##r##0] "=&v"(x[r][0]), [x##r##1] "=&v"(x[r][1]), [x##r##2] "=&v"(x[r][2]), [x##r##3] "=&v"(x[r][3]), \
+                      [m##r##0] "=&s"(m[r][0]), [m##r##1] "=&s"(m[r][1]), [m##r##2] "=&s"(m[r][2]), [m##r##3] "=&s"(m[r][3])
 #define SM_OUT_A [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [a3] "=&v"(a[3])
-#define SM_IN_ROW(r) [m##r##0] "s"(m[r][0]), [m##r##1] "s"(m[r][1]), [m##r##2] "s"(m[r][2]), [m##r##3] "s"(m[r][3])
-#define SM_IN_A [roff] "v"(roff), [xo0] "s"(xo[0]), [xo1] "s"(xo[1]), [xo2] "s"(xo[2]), [xo3] "s"(xo[3])
-#define SM_IN_VS [v0] "s"(sv[0]), [v1] "s"(sv[1]), [v2] "s"(sv[2]), [v3] "s"(sv[3])
-#define SM_IN_VV(r) [v##r##0] "v"(vv[r][0]), [v##r##1] "v"(vv[r][1]), [v##r##2] "v"(vv[r][2]), [v##r##3] "v"(vv[r][3])
-// the table's values as multipliers (scalar registers)
+#define SM_IN [roff] "v"(roff), [xo0] "s"(xo[0]), [xo1] "s"(xo[1]), [xo2] "s"(xo[2]), [xo3] "s"(xo[3]), [v0] "s"(sv[0]), [v1] "s"(sv[1]), [v2] "s"(sv[2]), [v3] "s"(sv[3])
 template <int R>
-__device__ __forceinline__ void sm_step(double (&acc)[R], unsigned roff, const unsigned (&xo)[4], const unsigned long long (&m)[R][4], const double (&sv)[4]) {
+__device__ __forceinline__ void sm_step(double (&acc)[R], uint32_t (&mk)[R], unsigned roff, const unsigned (&xo)[4], const double (&sv)[4]) {
     unsigned a[4];
     double x[R][4];
+    unsigned long long m[R][4];
     if constexpr (R == 1)
-        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_WAIT SM_MA_ROW_S(0) SM_END : SM_OUT_ROW(0), SM_OUT_A : SM_IN_A, SM_IN_ROW(0), SM_IN_VS);
+        asm volatile(SM_ADDR SM_BIT_ROW(0) SM_RD_ROW(0, 0) SM_WAIT SM_MA_ROW(0) SM_END : SM_OUT_ROW(0), SM_OUT_A : SM_IN);
     else if constexpr (R == 2)
-        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_WAIT SM_MA_ROW_S(0) SM_MA_ROW_S(1) SM_END
-                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_A : SM_IN_A, SM_IN_ROW(0), SM_IN_ROW(1), SM_IN_VS);
+        asm volatile(SM_ADDR SM_BIT_ROW(0) SM_BIT_ROW(1) SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_WAIT SM_MA_ROW(0) SM_MA_ROW(1) SM_END
+                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_A : SM_IN);
     else
-        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_RD_ROW(2, 1024) SM_RD_ROW(3, 1536) SM_WAIT SM_MA_ROW_S(0) SM_MA_ROW_S(1)
-                     SM_MA_ROW_S(2) SM_MA_ROW_S(3) SM_END
-                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_ROW(2), SM_OUT_ROW(3), SM_OUT_A
-                     : SM_IN_A, SM_IN_ROW(0), SM_IN_ROW(1), SM_IN_ROW(2), SM_IN_ROW(3), SM_IN_VS);
-}
-// a multiplier per row and pair (vector registers): the per-row diagonal values
-template <int R>
-__device__ __forceinline__ void sm_step_v(double (&acc)[R], unsigned roff, const unsigned (&xo)[4], const unsigned long long (&m)[R][4], const double (&vv)[R][4]) {
-    unsigned a[4];
-    double x[R][4];
-    if constexpr (R == 1)
-        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_WAIT SM_MA_ROW_V(0) SM_END : SM_OUT_ROW(0), SM_OUT_A : SM_IN_A, SM_IN_ROW(0), SM_IN_VV(0));
-    else if constexpr (R == 2)
-        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_WAIT SM_MA_ROW_V(0) SM_MA_ROW_V(1) SM_END
-                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_A : SM_IN_A, SM_IN_ROW(0), SM_IN_ROW(1), SM_IN_VV(0), SM_IN_VV(1));
-    else
-        asm volatile(SM_ADDR SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_RD_ROW(2, 1024) SM_RD_ROW(3, 1536) SM_WAIT SM_MA_ROW_V(0) SM_MA_ROW_V(1)
-                     SM_MA_ROW_V(2) SM_MA_ROW_V(3) SM_END
-                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_ROW(2), SM_OUT_ROW(3), SM_OUT_A
-                     : SM_IN_A, SM_IN_ROW(0), SM_IN_ROW(1), SM_IN_ROW(2), SM_IN_ROW(3), SM_IN_VV(0), SM_IN_VV(1), SM_IN_VV(2), SM_IN_VV(3));
+        asm volatile(SM_ADDR SM_BIT_ROW(0) SM_BIT_ROW(1) SM_BIT_ROW(2) SM_BIT_ROW(3) SM_RD_ROW(0, 0) SM_RD_ROW(1, 512) SM_RD_ROW(2, 1024)
+                     SM_RD_ROW(3, 1536) SM_WAIT SM_MA_ROW(0) SM_MA_ROW(1) SM_MA_ROW(2) SM_MA_ROW(3) SM_END
+                     : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_ROW(2), SM_OUT_ROW(3), SM_OUT_A : SM_IN);
 }
 
-template <int MODE, bool DIAG, int R, int NP, bool SMEM>
-__global__ __launch_bounds__(256) void spmv_sellmask_kernel(
+// NP > 0: the number of pairs, known at compile time.  SMEM: the pairs' constants come through scalar loads (else: lane e holds pair
+// e's, v_readlane).  WAVES waves of R slices each: a block of 64 WAVES R rows (the plan's 256-row blocks times WAVES R / 4).
+// LDS: 16 spare bytes, then the window.
+template <int MODE, int R, int NP, bool SMEM, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void spmv_sellmask_kernel(
     const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
-    double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const unsigned long long *__restrict__ masks,
-    const double *__restrict__ dict_g, const double *__restrict__ vdiag, int x_flags, const int16_t *__restrict__ blk_base, int pair_stride,
-    int n_pairs_arg, int diag_pair, const int32_t *__restrict__ own_rank) {
+    double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const uint32_t *__restrict__ masks,
+    const double *__restrict__ dict_g, int x_flags, const int32_t *__restrict__ blk_base32, int n_pairs_arg,
+    const int32_t *__restrict__ own_rank, int chain, long long *dbg) {
     const bool x_al16 = (x_flags & 1) != 0, nt_codes = (x_flags & 2) != 0;
     if (stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int b = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
-                                : (remap_arg < -1 ? xcd_group_remap(blockIdx.x, -remap_arg) : (int)blockIdx.x);
-    if (b >= n_blocks) return;
+    const int unit = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
+                                   : (remap_arg < -1 ? xcd_group_remap(blockIdx.x, -remap_arg) : (int)blockIdx.x);
+    // a workgroup walks `chain` consecutive blocks: what a block needs before its window can be requested -- the header -- and its
+    // masks and pair bases are loaded while the block before it computes (only the first block of a workgroup pays for the header trip:
+    // ~1600 of a block's ~12000 cycles; the registers this takes are free here -- the window in LDS, not registers, bounds the occupancy)
+    const int b_first = unit * chain, b_end = min(b_first + chain, n_blocks);
+    if (b_first >= n_blocks) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_pairs = NP > 0 ? NP : n_pairs_arg;
-    const int hw = hdr[(size_t)b * 64 + lane];
-    const int64_t slice0 = ((int64_t)b * 4 + wv) * R;
-    // lane e (+ 32 for the wave's second slice): which rows of the slice have pair e
-    constexpr int TV = (R + 1) / 2;
-    unsigned long long tv[TV];
+    struct Blk { int hw; uint32_t mk[R]; int pxo; int own; };
+    auto load_blk = [&](int b, Blk &k) {
+        k.hw = hdr[(size_t)b * 64 + lane];
+        const int64_t slice0 = ((int64_t)b * WAVES + wv) * R;
 #pragma unroll
-    for (int h = 0; h < TV; ++h) {
-        tv[h] = 0ull;
-        const unsigned long long *mp = &masks[(slice0 + 2 * h) * 32 + lane];
-        if (!SMEM && lane < 32 * min(R - 2 * h, 2)) tv[h] = nt_codes ? __builtin_nontemporal_load(mp) : *mp;
-    }
-    // pair `lane`: its value and where its column for the block's first row lies in LDS
-    double pv = 0.0;
-    int pxo = 0;
-    const int32_t *__restrict__ bb32 = reinterpret_cast<const int32_t *>(blk_base) + (size_t)b * 32;
-    if (!SMEM && lane < n_pairs) {
-        pv = dict_g[lane];
-        pxo = bb32[lane];
-    }
-    double wr[R], dval[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t row = (slice0 + r) * 64 + lane;
-        wr[r] = 0.0;
-        if (MODE == 1 && !own_rank && row < n_rows) wr[r] = w[row];
-        if (DIAG) dval[r] = row < n_rows ? vdiag[row] : 0.0;
-    }
-    int own = -1;
-    if (MODE == 1 && own_rank) {
-        own = own_rank[b];
-        if (own < 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) { const int64_t row = (slice0 + r) * 64 + lane; if (row < n_rows) wr[r] = w[row]; }
+        for (int r = 0; r < R; ++r) {
+            const uint32_t *mp = &masks[(slice0 + r) * 64 + lane]; // (the array is padded to whole blocks)
+            k.mk[r] = nt_codes ? __builtin_nontemporal_load(mp) : *mp;
         }
-    }
-    { // the window: as in spmv_sellwin_kernel
-        const int n_runs = __popcll(__ballot(lane >= 32 && (hw >> 16) != 0));
-        unsigned char *win = lds + 16;
-        for (int k = 0; k < n_runs; ++k) {
-            const int g0 = __builtin_amdgcn_readlane(hw, k);
-            const int w2 = __builtin_amdgcn_readlane(hw, 32 + k);
-            const int rank = w2 & 0xffff, n_pieces = (w2 >> 16) * 4;
-            const int j = (wv + k) & 3;
-            const int p = j * 64 + lane;
-            const int64_t c = (int64_t)g0 * 8 + 2 * p;
-            unsigned char *dst = win + (size_t)rank * 64 + (size_t)j * 1024;
-            if (p < n_pieces) {
-                if (x_al16 && c + 1 < n_cols) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + c),
-                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-                } else {
-                    double2 v;
-                    v.x = c < n_cols ? x[c] : 0.0;
-                    v.y = c + 1 < n_cols ? x[c + 1] : 0.0;
-                    *reinterpret_cast<double2 *>(dst + lane * 16) = v;
+        k.pxo = (!SMEM && lane < n_pairs) ? blk_base32[(size_t)b * 32 + lane] : 0; // pair `lane`: where its column for the block's first row lies in LDS
+        k.own = (MODE == 1 && own_rank) ? own_rank[b] : -1;
+    };
+    const double pv = (!SMEM && lane < n_pairs) ? dict_g[lane] : 0.0; // pair `lane`: its value
+    const unsigned pv_lo = (unsigned)(unsigned long long)__double_as_longlong(pv), pv_hi = (unsigned)((unsigned long long)__double_as_longlong(pv) >> 32);
+    const unsigned row_off0 = (unsigned)((wv * R * 64 + lane) * 8); // (the wave's slice r: + 512 r)
+    Blk cb, nb;
+    load_blk(b_first, cb);
+    nb = cb;
+    for (int b = b_first; b < b_end; ++b) {
+        const long long t_start = dbg ? (long long)__builtin_readcyclecounter() : 0; // diagnostic stamps (BIS_SELLWIN_DEBUG): shader cycles
+        const int64_t slice0 = ((int64_t)b * WAVES + wv) * R;
+        const int32_t *__restrict__ bb32 = blk_base32 + (size_t)b * 32;
+        const int hw = cb.hw, pxo = cb.pxo, own = cb.own;
+        uint32_t mk[R];
+        double wr[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mk[r] = cb.mk[r];
+            wr[r] = 0.0;
+            const int64_t row = (slice0 + r) * 64 + lane;
+            if (MODE == 1 && own < 0 && row < n_rows) wr[r] = w[row];
+        }
+        { // the window: as in spmv_sellwin_kernel
+            const int n_runs = __popcll(__ballot(lane >= 32 && (hw >> 16) != 0));
+            if (dbg && tid == 0) dbg[(size_t)b * 4 + 1] = (long long)__builtin_readcyclecounter() - t_start; // header arrived
+            unsigned char *win = lds + 16;
+            for (int k = wv >> 2; k < n_runs; k += WAVES / 4) { // (a run is four pieces of 64 x 16 bytes at most: a wave each; eight waves: every other run)
+                const int g0 = __builtin_amdgcn_readlane(hw, k);
+                const int w2 = __builtin_amdgcn_readlane(hw, 32 + k);
+                const int rank = w2 & 0xffff, n_pieces = (w2 >> 16) * 4;
+                const int j = (wv + k) & 3;
+                const int p = j * 64 + lane;
+                const int64_t c = (int64_t)g0 * 8 + 2 * p;
+                unsigned char *dst = win + (size_t)rank * 64 + (size_t)j * 1024;
+                if (p < n_pieces) {
+                    if (x_al16 && c + 1 < n_cols) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + c),
+                                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                    } else {
+                        double2 v;
+                        v.x = c < n_cols ? x[c] : 0.0;
+                        v.y = c + 1 < n_cols ? x[c + 1] : 0.0;
+                        *reinterpret_cast<double2 *>(dst + lane * 16) = v;
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    double acc[R];
+        if (b + 1 < b_end) load_blk(b + 1, nb); // (behind the window's requests; arrives with them)
+        __syncthreads();
+        if (dbg && tid == 0) dbg[(size_t)b * 4 + 2] = (long long)__builtin_readcyclecounter() - t_start; // window arrived, barrier passed
+        double acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0;
-    const unsigned row_off0 = (unsigned)((wv * R * 64 + lane) * 8); // (the wave's slice r: + 512 r)
-    const unsigned pv_lo = (unsigned)(unsigned long long)__double_as_longlong(pv), pv_hi = (unsigned)((unsigned long long)__double_as_longlong(pv) >> 32);
-    // four pairs a step, the next step's scalars loaded (SMEM) before this step's LDS reads are waited for
-    struct Step { unsigned xo[4]; double sv[4]; unsigned long long m[R][4]; };
-    auto fetch = [&](int e0, Step &g) { // pairs e0 .. e0 + 3 (those past the last have empty masks)
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+        // four pairs a step; SMEM: the next step's constants are loaded before this step's LDS reads are waited for
+        struct Step { unsigned xo[4]; double sv[4]; };
+        auto fetch = [&](int e0, Step &g) { // pairs e0 .. e0 + 3 (no row has the ones past the last)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = min(e0 + q, 31);
-            if (SMEM) {
-                g.xo[q] = (unsigned)bb32[e];
-                g.sv[q] = dict_g[e];
-            } else {
-                g.xo[q] = (unsigned)__builtin_amdgcn_readlane(pxo, e);
-                g.sv[q] = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)pv_hi, e) << 32) |
-                                                           (unsigned)__builtin_amdgcn_readlane((int)pv_lo, e)));
+            for (int q = 0; q < 4; ++q) {
+                const int e = min(e0 + q, 31);
+                if (SMEM) {
+                    g.xo[q] = (unsigned)bb32[e];
+                    g.sv[q] = dict_g[e];
+                } else {
+                    g.xo[q] = (unsigned)__builtin_amdgcn_readlane(pxo, e);
+                    g.sv[q] = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)pv_hi, e) << 32) |
+                                                               (unsigned)__builtin_amdgcn_readlane((int)pv_lo, e)));
+                }
             }
+        };
+        Step cur, nxt;
+        fetch(0, cur);
+        if constexpr (NP > 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (e0 + q >= 32) g.m[r][q] = 0ull;
-                else if (SMEM) g.m[r][q] = masks[(slice0 + r) * 32 + e];
-                else g.m[r][q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(tv[r / 2] >> 32), (r & 1) * 32 + e) << 32) |
-                                 (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tv[r / 2], (r & 1) * 32 + e);
+            for (int e0 = 0; e0 < NP; e0 += 4) {
+                // (this step's scalars have arrived -- the step before waited for everything -- but the compiler does not see waits inside
+                // the hand-written steps: told here, it does not put its own wait BEHIND the next fetch)
+                if (SMEM) __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+                if (e0 + 4 < NP) fetch(e0 + 4, nxt);
+                sm_step<R>(acc, mk, row_off0, cur.xo, cur.sv);
+                cur = nxt;
             }
-        }
-    };
-    auto apply = [&](int e0, const Step &g) {
-        if constexpr (DIAG) { // the diagonal pair's value is the row's own
-            double vv[R][4];
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) vv[r][q] = e0 + q == diag_pair ? dval[r] : g.sv[q];
-            sm_step_v<R>(acc, row_off0, g.xo, g.m, vv);
         } else {
-            sm_step<R>(acc, row_off0, g.xo, g.m, g.sv);
+            for (int e0 = 0; e0 < n_pairs; e0 += 4) {
+                if (SMEM) __builtin_amdgcn_s_waitcnt(0xc07f);
+                fetch(min(e0 + 4, 28), nxt); // (past the last pair: fetched, not used)
+                sm_step<R>(acc, mk, row_off0, cur.xo, cur.sv);
+                cur = nxt;
+            }
         }
-    };
-    Step cur, nxt;
-    fetch(0, cur);
-    if constexpr (NP > 0) {
 #pragma unroll
-        for (int e0 = 0; e0 < NP; e0 += 4) {
-            // (this step's scalars have arrived -- the step before waited for everything -- but the compiler does not see waits inside
-            // the hand-written steps: told here, it does not put its own wait BEHIND the next fetch)
-            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
-            if (e0 + 4 < NP) fetch(e0 + 4, nxt);
-            apply(e0, cur);
-            cur = nxt;
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = (slice0 + r) * 64 + lane;
+            if (row < n_rows) y[row] = acc[r];
+            if (MODE == 1) {
+                if (own >= 0) wr[r] = *reinterpret_cast<const double *>(lds + 16 + ((size_t)own * 8 + (wv * R + r) * 64 + lane) * 8);
+                const double t = wave_sum(row < n_rows ? acc[r] * wr[r] : 0.0);
+                if (lane == 0) partials[slice0 + r] = t;
+            }
         }
-    } else {
-        for (int e0 = 0; e0 < n_pairs; e0 += 4) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            fetch(min(e0 + 4, 28), nxt); // (past the last pair: fetched, not used)
-            apply(e0, cur);
-            cur = nxt;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t row = (slice0 + r) * 64 + lane;
-        if (row < n_rows) y[row] = acc[r];
-        if (MODE == 1) {
-            if (own >= 0) wr[r] = *reinterpret_cast<const double *>(lds + 16 + ((size_t)own * 8 + (wv * R + r) * 64 + lane) * 8);
-            const double t = wave_sum(row < n_rows ? acc[r] * wr[r] : 0.0);
-            if (lane == 0) partials[slice0 + r] = t;
-        }
+        if (dbg && tid == 0) { dbg[(size_t)b * 4 + 3] = (long long)__builtin_readcyclecounter() - t_start; dbg[(size_t)b * 4] = t_start; }
+        if (b + 1 < b_end) __syncthreads(); // (the window is the next block's from here on)
+        cb = nb;
     }
 }
 
@@ -936,6 +902,7 @@ __global__ __launch_bounds__(256) void spmv_sellmask_kernel(
 // leaves three workgroups = three waves per SIMD, and the computation -- two dependent LDS round trips per four non-zeros
 // -- needs the six waves per SIMD of the single-buffer kernel to cover its own LDS latency.)
 bool sw_enabled() { return bis_opts().spmv_sellwin != 0; }
+int sw_mask_chain() { const int c = bis_opts().spmv_sellwin_chain; return c > 0 ? std::min(c, 64) : 1; } // fmt 4: blocks a workgroup walks (measured: 1 / 2 / 4 / 8 -> 0.118 / 0.115 / 0.123 / 0.125 ms at HPCG-256 -- hiding the header trip buys nothing, the kernel is not latency-bound)
 
 } // namespace
 
@@ -1010,7 +977,8 @@ static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, in
     const int stride = (n_pairs + 63) / 64 * 64;
     const int nb = sw->n_blocks;
     // fmt 4 (a mask per row) where the pairs fit 32 bits and the rows run through them in order, else fmt 3 (a byte per non-zero)
-    for (int attempt = (n_pairs <= 32 && bis_opts().spmv_sellwin_masks != 0) ? 0 : 1; attempt < 2; ++attempt) {
+    // (not with per-row diagonal values: a multiplier per row and pair in vector registers measured slower than the byte codes, Anderson-256 0.140 against 0.109 ms)
+    for (int attempt = (n_pairs <= 32 && diag_pair < 0 && bis_opts().spmv_sellwin_masks != 0) ? 0 : 1; attempt < 2; ++attempt) {
         const bool masks = attempt == 0;
         const int64_t total = sw->total_chunks;
         const size_t code_words = masks ? (size_t)nb * 256 * (size_t)sw->R : 64 * (size_t)(total + 1);
@@ -1028,7 +996,7 @@ static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, in
         if (e == hipSuccess && !masks) e = hipMemsetAsync(codes + (size_t)total * 64, 0, sizeof(uint32_t) * 64, ctx->stream);
         if (e == hipSuccess) {
 #define SW_FILLP(RP) hipLaunchKernelGGL((sw_fill_pairs_kernel<RP>), dim3(nb), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, A->view_row0, sw->R, sw->hdr, sw->slice_chunk0, codes, pair_key, n_pairs, stride, blk_base, status)
-#define SW_FILLM(RP) hipLaunchKernelGGL((sw_fill_masks_kernel<RP>), dim3(nb), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, A->view_row0, sw->R, sw->hdr, (unsigned long long *)codes, pair_key, n_pairs, stride, blk_base, status)
+#define SW_FILLM(RP) hipLaunchKernelGGL((sw_fill_masks_kernel<RP>), dim3(nb), dim3(256), 0, ctx->stream, (const RP *)A->row_ptr, A->col, A->vcode, A->vd_base, A->n_rows, A->view_row0, sw->R, sw->hdr, codes, pair_key, n_pairs, stride, blk_base, status)
             if (masks) { if (A->rp64) SW_FILLM(int64_t); else SW_FILLM(int32_t); }
             else { if (A->rp64) SW_FILLP(int64_t); else SW_FILLP(int32_t); }
 #undef SW_FILLP
@@ -1063,13 +1031,30 @@ static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, in
 }
 
 // Build the form for a matrix that has a value dictionary (A->vd_state == 1); A->sw_state tells the outcome.
+static bis_status sw_try_rows(bis_ctx *ctx, bis_mat *A, int R);
+
 bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     if (A->sw_state != 0) return BIS_OK;
     A->sw_state = -1;
     if (!sw_enabled() || A->vd_state != 1 || A->n_rows == 0 || A->nnz == 0 || A->n_cols >= ((int64_t)1 << 31) - 16) return BIS_OK;
     int R = kSwDefaultR;
     while (R > 1 && A->n_rows < (int64_t)kSwRows * R * 1024) R >>= 1; // small matrices: more, smaller blocks
-    if (bis_opts().spmv_sellwin_rows > 0) R = bis_opts().spmv_sellwin_rows >= 4 ? 4 : (bis_opts().spmv_sellwin_rows >= 2 ? 2 : 1);
+    bool big = R == 2 && A->n_rows >= (int64_t)kSwRows * 4 * 1024;
+    if (bis_opts().spmv_sellwin_rows > 0) {
+        R = bis_opts().spmv_sellwin_rows >= 2 ? 2 : 1;
+        big = bis_opts().spmv_sellwin_rows >= 4;
+    }
+    // Blocks of 1024 rows exist for the row-mask form only (its waves keep 4 x 4 LDS reads in flight: HPCG-256 0.116 against 0.125 ms
+    // with 512 rows): tried first where that form can apply, and the plan is redone with 512 rows where it then does not.
+    if (big && !A->vd_diag && bis_opts().spmv_sellwin_masks != 0 && bis_opts().spmv_sellwin_pairs != 0) {
+        if (bis_status st = sw_try_rows(ctx, A, 4)) return st;
+        if (A->sw_state == 1) return BIS_OK;
+        A->sw_state = -1;
+    }
+    return sw_try_rows(ctx, A, R);
+}
+
+static bis_status sw_try_rows(bis_ctx *ctx, bis_mat *A, int R) {
     const int64_t nb64 = (A->n_rows + (int64_t)kSwRows * R - 1) / ((int64_t)kSwRows * R);
     if (nb64 > (int64_t)1 << 26) return BIS_OK;
     const int nb = (int)nb64;
@@ -1169,7 +1154,11 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     return BIS_OK;
 }
 
-int bis_spmv_sellwin_blocks(const bis_mat *A) { return A->sw_state == 1 ? A->sw->n_blocks : 0; }
+// launch units: blocks, or (fmt 4) workgroups that walk sw_mask_chain() blocks each
+int bis_spmv_sellwin_blocks(const bis_mat *A) {
+    if (A->sw_state != 1) return 0;
+    return A->sw->fmt == 4 ? (A->sw->n_blocks + sw_mask_chain() - 1) / sw_mask_chain() : A->sw->n_blocks;
+}
 int64_t bis_spmv_sellwin_slices(const bis_mat *A) { return A->sw_state == 1 ? A->sw->n_slices : 0; }
 int bis_spmv_sellwin_format(const bis_mat *A) { return A->sw_state == 1 ? A->sw->fmt : -1; }
 
@@ -1200,24 +1189,21 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
     }
     const int32_t *own = (mode == 1 && w == x + A->view_row0 && x_al16) ? sw->own_rank : nullptr; // the fused dot's w is x itself (CG: p)
     if (sw->fmt == 4) {
-#define SM_L3(MODE, DIAG, RR, NN)                                                                                          \
-    hipLaunchKernelGGL((spmv_sellmask_kernel<MODE, DIAG, RR, NN, false>), dim3(grid), dim3(256), win, ctx->stream, x, y, A->n_rows, A->n_cols, \
-                       sw->n_blocks, remap_arg, w, partials, stop, sw->hdr, (const unsigned long long *)sw->codes, sw->dict, A->vdiag, \
-                       x_al16 | (bis_opts().spmv_sellwin_nt != 0 ? 2 : 0), sw->blk_base, sw->pair_stride, sw->n_pairs, sw->diag_pair, own)
-#define SM_L2(MODE, DIAG) do {                                                                                             \
-        if (sw->R == 4 && sw->n_pairs == 27) SM_L3(MODE, DIAG, 4, 27);                                                     \
-        else if (sw->R == 4) SM_L3(MODE, DIAG, 4, 0);                                                                      \
-        else if (sw->R == 2 && sw->n_pairs == 27) SM_L3(MODE, DIAG, 2, 27);                                                \
-        else if (sw->R == 2 && sw->n_pairs == 7) SM_L3(MODE, DIAG, 2, 7);                                                  \
-        else if (sw->R == 2) SM_L3(MODE, DIAG, 2, 0); else SM_L3(MODE, DIAG, 1, 0); } while (0)
-#define SM_L1(MODE) do { if (sw->diag) SM_L2(MODE, true); else SM_L2(MODE, false); } while (0)
-        if (mode == 1) SM_L1(1); else SM_L1(0);
-#undef SM_L1
+#define SM_L4(MODE, RR, NN, SM, WV)                                                                                        \
+    hipLaunchKernelGGL((spmv_sellmask_kernel<MODE, RR, NN, SM, WV>), dim3(grid), dim3(64 * WV), win, ctx->stream, x, y, A->n_rows, A->n_cols, \
+                       sw->n_blocks, remap_arg, w, partials, stop, sw->hdr, sw->codes, sw->dict, x_al16 | (bis_opts().spmv_sellwin_nt != 0 ? 2 : 0), \
+                       (const int32_t *)sw->blk_base, sw->n_pairs, own, sw_mask_chain(), dbg)
+#define SM_L3(MODE, RR, NN) do { if (bis_opts().spmv_sellwin_smem > 0) SM_L4(MODE, RR, NN, true, 4); else SM_L4(MODE, RR, NN, false, 4); } while (0)
+#define SM_L2(MODE) do {                                                                                                   \
+        if (sw->R == 4 && sw->n_pairs == 27) SM_L3(MODE, 4, 27);                                                           \
+        else if (sw->R == 4) SM_L3(MODE, 4, 0);                                                                            \
+        else if (sw->R == 2 && sw->n_pairs == 27) SM_L3(MODE, 2, 27);                                                      \
+        else if (sw->R == 2) SM_L3(MODE, 2, 0); else SM_L3(MODE, 1, 0); } while (0)
+        if (mode == 1) SM_L2(1); else SM_L2(0);
 #undef SM_L2
 #undef SM_L3
-        BIS_HIP_CHECK(ctx, hipGetLastError());
-        return BIS_OK;
-    }
+#undef SM_L4
+    } else {
 #define SW_L4(MODE, DIAG, FMT, RR)                                                                                     \
     hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, FMT, RR>), dim3(grid), dim3(256), (FMT == 3 ? win_off3 : (size_t)(SwLayout<DIAG, FMT, RR>::kWinOff)) + win, \
                        ctx->stream, x, y, A->n_rows, A->n_cols, sw->n_blocks, remap_arg, w, partials, stop, sw->hdr,   \
@@ -1238,6 +1224,7 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
 #undef SW_L3
 #undef SW_L4
 #undef SW_L4N
+    }
     BIS_HIP_CHECK(ctx, hipGetLastError());
     if (dbg) {
         std::vector<long long> hd((size_t)4 * sw->n_blocks);

@@ -122,7 +122,7 @@ def cg_leg(E, args, n1, matrix, precond, shift, steps, warmup, valdict):
     comm = d.profile_read()
     iters, conv, hist = cg.status(hist_cap=warmup + steps + 1)
     col_b, val_b, n_dict, form = d.spmv_stream_info()
-    kernel = KERNELS[form]
+    kernel = "spmv_sellmask_kernel" if form >= 4 and col_b == 0 else KERNELS[form]
     streamed = d.spmv_streamed_bytes()
     crs_local = 12 * nnz_local + 20 * nl  # this rank's share of SURVEY 8d's algorithmic bytes
     spmv_s = max(spmv_ms / max(steps, 1), 1e-9) * 1e-3

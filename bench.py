@@ -127,7 +127,8 @@ def stream_format(A):
     """What the SpMV streams for this matrix (bis_mat_spmv_stream_info / bis_mat_spmv_streamed_bytes)."""
     col_b, val_b, n_dict, form = A.spmv_stream_info()
     return {"col_bytes": col_b, "val_bytes": val_b, "dictionary_values": n_dict, "form": form,
-            "kernel": KERNEL_OF_FORM[form], "streamed_bytes_per_nnz": col_b + val_b,
+            "kernel": "spmv_sellmask_kernel" if form >= 4 and col_b == 0 else KERNEL_OF_FORM[form],  # (form 4 without per-non-zero codes: the row-mask kernel)
+            "streamed_bytes_per_nnz": col_b + val_b,
             "streamed_bytes_per_launch": A.spmv_streamed_bytes()}
 
 

@@ -1300,7 +1300,7 @@ def _banded_few_values(rng, n, n_values, offsets, max_len, ragged=4, empty_every
     return CRS(n, rp, col, val, n_cols=n_cols)
 
 
-@pytest.mark.parametrize("rp64,rows,joint,pairs,masks", [(0, 1, -1, -1, -1), (1, 2, -1, -1, -1), (0, 2, -1, -1, 0), (1, 1, -1, -1, 0), (0, 2, -1, 0, -1),
+@pytest.mark.parametrize("rp64,rows,joint,pairs,masks", [(0, 1, -1, -1, -1), (1, 2, -1, -1, -1), (0, 4, -1, -1, -1), (1, 4, -1, -1, -1), (0, 2, -1, -1, 0), (1, 1, -1, -1, 0), (0, 2, -1, 0, -1),
                                                          (1, 1, -1, 0, -1), (0, 2, 0, 0, -1), (1, 1, 0, 0, -1)])
 def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pairs, masks):
     """Forms 4 / 5 of the dictionary SpMV (bis_spmv_sell.hip): the block's x entries in an LDS window, the codes per
@@ -1308,8 +1308,8 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pair
     within the kernel tolerance of the oracle (kernels.hpp:22-42): stencils, banded matrices with several column runs,
     ragged and empty rows, -0.0 / denormal / huge values and -0.0 row sums (the padding must not turn them into +0.0),
     dictionaries of <= 32 and of up to 255 values, the per-row diagonal form, odd sizes (a window granule that reaches
-    past the last column), an x that is only 8-byte aligned, 64-bit row pointers; blocks of 256 and of 512 rows
-    (option spmv_sellwin_rows); the one-byte (column - row, value) pair codes of stencil matrices (at most 253 pairs,
+    past the last column), an x that is only 8-byte aligned, 64-bit row pointers; blocks of 256, of 512 and (the row-mask form
+    only; other matrices then get 512) of 1024 rows (option spmv_sellwin_rows); the one-byte (column - row, value) pair codes of stencil matrices (at most 253 pairs,
     each running through every block's window in step with the rows; a pair with a gap in its run inside a block, or
     too many pairs, takes the next format: spmv_sellwin_pairs 0 forces that), in their place 32 bits per ROW -- which of the matrix'
     pairs the row has -- where the matrix has at most 32 pairs and the rows' columns ascend (spmv_sellwin_masks 0: never), the 16-bit joint codes (tables of at most
@@ -1366,7 +1366,7 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pair
                         stencil = name.startswith(("hpcg", "anderson", "-0.0", "one row"))
                         few = A.nnz > 0 and len(np.unique(A.val.view(np.uint64))) <= 6 and want == 4
                         if stencil and pairs != 0:
-                            if masks != 0 and name.startswith(("hpcg", "anderson")):
+                            if masks != 0 and name.startswith(("hpcg", "anderson")) and want == 4:
                                 assert info[:2] == (0, 0), (name, info)  # nothing per non-zero: 32 bits per row
                             else:
                                 assert info[:2] in ((1, 0), (0, 0)) and (masks != 0 or info[0] == 1), (name, info)
@@ -1402,7 +1402,7 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pair
         ctx.set_option("spmv_sellwin_masks", -1)
 
 
-@pytest.mark.parametrize("rows,masks", [(1, -1), (2, -1), (2, 0)])
+@pytest.mark.parametrize("rows,masks", [(1, -1), (2, -1), (4, -1), (2, 0)])
 def test_spmv_sellwin_in_fused_cg(ctx, oracle, rows, masks):
     """The fused (Ap, p) epilogue of form 4 sums over the same 256-row blocks and waves as the lane-per-row gather
     form: the CG history is bit-identical to it, and within 1e-10 r0 of the oracle's (methods/cg.hpp:6-54);
