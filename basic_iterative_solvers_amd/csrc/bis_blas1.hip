@@ -302,9 +302,6 @@ bis_status bis_set_option(const char *name, int value) {
     else if (!strcmp(name, "spmv_sellwin_joint")) o.spmv_sellwin_joint = value;
     else if (!strcmp(name, "spmv_sellwin_pairs")) o.spmv_sellwin_pairs = value;
     else if (!strcmp(name, "spmv_sellwin_masks")) o.spmv_sellwin_masks = value;
-    else if (!strcmp(name, "spmv_sellwin_chain")) o.spmv_sellwin_chain = value;
-    else if (!strcmp(name, "spmv_sellwin_waves")) o.spmv_sellwin_waves = value;
-    else if (!strcmp(name, "spmv_sellwin_smem")) o.spmv_sellwin_smem = value;
     else if (!strcmp(name, "grid_autodetect")) o.grid_autodetect = value;
     else if (!strcmp(name, "tune_placement")) o.tune_placement = value;
     else if (!strcmp(name, "cg_graph")) o.cg_graph = value;

@@ -99,9 +99,6 @@ struct bis_options {
     int spmv_sellwin_rows = -1; // rows per lane of the sliced-ELL form: 1 or 2 (blocks of 256 or 512 rows; -1: default 2)
     int spmv_sellwin_pairs = -1; // 0: never the one-byte (column - row, value) pair codes
     int spmv_sellwin_joint = -1; // 0: never the 16-bit joint (slot, value) codes
-    int spmv_sellwin_smem = -1; // row-mask form: 1 = masks and pair constants through scalar loads (default: a vector load and v_readlane)
-    int spmv_sellwin_waves = -1; // row-mask form, blocks of 1024 rows: 4 = four waves of four slices (default: eight waves of two)
-    int spmv_sellwin_chain = -1; // row-mask form: consecutive blocks a workgroup walks, the next block's header / masks loaded under the current one (default 1: no gain measured)
     int spmv_sellwin_masks = -1; // 0: never the per-row pair masks (fmt 4: 4 bytes per ROW where the matrix has at most 32 (column - row, value) pairs)
     int device_share = -1;  // k > 1: this device is shared by k processes that all run persistent grids (several ranks on one GPU in a test
                             // or rehearsal): kernels that need their whole grid resident keep to 1/k of the device

@@ -751,141 +751,117 @@ __device__ __forceinline__ void sm_step(double (&acc)[R], uint32_t (&mk)[R], uns
                      : SM_OUT_ROW(0), SM_OUT_ROW(1), SM_OUT_ROW(2), SM_OUT_ROW(3), SM_OUT_A : SM_IN);
 }
 
-// NP > 0: the number of pairs, known at compile time.  SMEM: the pairs' constants come through scalar loads (else: lane e holds pair
-// e's, v_readlane).  WAVES waves of R slices each: a block of 64 WAVES R rows (the plan's 256-row blocks times WAVES R / 4).
-// LDS: 16 spare bytes, then the window.
-template <int MODE, int R, int NP, bool SMEM, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void spmv_sellmask_kernel(
+// NP > 0: the number of pairs, known at compile time.  Four waves of R slices each: a block of 256 R rows.  LDS: 16 spare bytes,
+// then the window.
+// (Measured and removed: the pairs' constants and / or transposed per-slice masks through scalar loads instead of v_readlane /
+// v_add_co -- 0.150 against 0.135 ms at HPCG-256, the scalar loads' latency is not hidden; eight waves of two slices on the
+// 1024-row block -- 0.131 against 0.124; a workgroup walking 2 / 4 / 8 consecutive blocks with the next block's header, masks and
+// bases loaded under the current one -- 0.115 / 0.123 / 0.125 against 0.118: the header trip disappears from the stamps and the
+// block's life stays the same.  rocprofv3 (profiles/r04_e_spmv_pmc_sellmask.txt): 11 instructions per non-zero and wave -- 5.4
+// vector, 4.8 scalar (the execution-mask moves), 1 LDS -- at 3.4 waves per SIMD: instruction issue, not a memory pipe, paces it.)
+template <int MODE, int R, int NP>
+__global__ __launch_bounds__(256) void spmv_sellmask_kernel(
     const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
     double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const uint32_t *__restrict__ masks,
     const double *__restrict__ dict_g, int x_flags, const int32_t *__restrict__ blk_base32, int n_pairs_arg,
-    const int32_t *__restrict__ own_rank, int chain, long long *dbg) {
+    const int32_t *__restrict__ own_rank, long long *dbg) {
     const bool x_al16 = (x_flags & 1) != 0, nt_codes = (x_flags & 2) != 0;
     if (stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int unit = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
-                                   : (remap_arg < -1 ? xcd_group_remap(blockIdx.x, -remap_arg) : (int)blockIdx.x);
-    // a workgroup walks `chain` consecutive blocks: what a block needs before its window can be requested -- the header -- and its
-    // masks and pair bases are loaded while the block before it computes (only the first block of a workgroup pays for the header trip:
-    // ~1600 of a block's ~12000 cycles; the registers this takes are free here -- the window in LDS, not registers, bounds the occupancy)
-    const int b_first = unit * chain, b_end = min(b_first + chain, n_blocks);
-    if (b_first >= n_blocks) return;
+    const int b = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
+                                : (remap_arg < -1 ? xcd_group_remap(blockIdx.x, -remap_arg) : (int)blockIdx.x);
+    if (b >= n_blocks) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_pairs = NP > 0 ? NP : n_pairs_arg;
-    struct Blk { int hw; uint32_t mk[R]; int pxo; int own; };
-    auto load_blk = [&](int b, Blk &k) {
-        k.hw = hdr[(size_t)b * 64 + lane];
-        const int64_t slice0 = ((int64_t)b * WAVES + wv) * R;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t *mp = &masks[(slice0 + r) * 64 + lane]; // (the array is padded to whole blocks)
-            k.mk[r] = nt_codes ? __builtin_nontemporal_load(mp) : *mp;
-        }
-        k.pxo = (!SMEM && lane < n_pairs) ? blk_base32[(size_t)b * 32 + lane] : 0; // pair `lane`: where its column for the block's first row lies in LDS
-        k.own = (MODE == 1 && own_rank) ? own_rank[b] : -1;
-    };
-    const double pv = (!SMEM && lane < n_pairs) ? dict_g[lane] : 0.0; // pair `lane`: its value
-    const unsigned pv_lo = (unsigned)(unsigned long long)__double_as_longlong(pv), pv_hi = (unsigned)((unsigned long long)__double_as_longlong(pv) >> 32);
-    const unsigned row_off0 = (unsigned)((wv * R * 64 + lane) * 8); // (the wave's slice r: + 512 r)
-    Blk cb, nb;
-    load_blk(b_first, cb);
-    nb = cb;
-    for (int b = b_first; b < b_end; ++b) {
-        const long long t_start = dbg ? (long long)__builtin_readcyclecounter() : 0; // diagnostic stamps (BIS_SELLWIN_DEBUG): shader cycles
-        const int64_t slice0 = ((int64_t)b * WAVES + wv) * R;
-        const int32_t *__restrict__ bb32 = blk_base32 + (size_t)b * 32;
-        const int hw = cb.hw, pxo = cb.pxo, own = cb.own;
-        uint32_t mk[R];
-        double wr[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            mk[r] = cb.mk[r];
-            wr[r] = 0.0;
-            const int64_t row = (slice0 + r) * 64 + lane;
-            if (MODE == 1 && own < 0 && row < n_rows) wr[r] = w[row];
-        }
-        { // the window: as in spmv_sellwin_kernel
-            const int n_runs = __popcll(__ballot(lane >= 32 && (hw >> 16) != 0));
-            if (dbg && tid == 0) dbg[(size_t)b * 4 + 1] = (long long)__builtin_readcyclecounter() - t_start; // header arrived
-            unsigned char *win = lds + 16;
-            for (int k = wv >> 2; k < n_runs; k += WAVES / 4) { // (a run is four pieces of 64 x 16 bytes at most: a wave each; eight waves: every other run)
-                const int g0 = __builtin_amdgcn_readlane(hw, k);
-                const int w2 = __builtin_amdgcn_readlane(hw, 32 + k);
-                const int rank = w2 & 0xffff, n_pieces = (w2 >> 16) * 4;
-                const int j = (wv + k) & 3;
-                const int p = j * 64 + lane;
-                const int64_t c = (int64_t)g0 * 8 + 2 * p;
-                unsigned char *dst = win + (size_t)rank * 64 + (size_t)j * 1024;
-                if (p < n_pieces) {
-                    if (x_al16 && c + 1 < n_cols) {
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + c),
-                                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-                    } else {
-                        double2 v;
-                        v.x = c < n_cols ? x[c] : 0.0;
-                        v.y = c + 1 < n_cols ? x[c + 1] : 0.0;
-                        *reinterpret_cast<double2 *>(dst + lane * 16) = v;
-                    }
-                }
-            }
-        }
-        if (b + 1 < b_end) load_blk(b + 1, nb); // (behind the window's requests; arrives with them)
-        __syncthreads();
-        if (dbg && tid == 0) dbg[(size_t)b * 4 + 2] = (long long)__builtin_readcyclecounter() - t_start; // window arrived, barrier passed
-        double acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.0;
-        // four pairs a step; SMEM: the next step's constants are loaded before this step's LDS reads are waited for
-        struct Step { unsigned xo[4]; double sv[4]; };
-        auto fetch = [&](int e0, Step &g) { // pairs e0 .. e0 + 3 (no row has the ones past the last)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = min(e0 + q, 31);
-                if (SMEM) {
-                    g.xo[q] = (unsigned)bb32[e];
-                    g.sv[q] = dict_g[e];
-                } else {
-                    g.xo[q] = (unsigned)__builtin_amdgcn_readlane(pxo, e);
-                    g.sv[q] = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)pv_hi, e) << 32) |
-                                                               (unsigned)__builtin_amdgcn_readlane((int)pv_lo, e)));
-                }
-            }
-        };
-        Step cur, nxt;
-        fetch(0, cur);
-        if constexpr (NP > 0) {
-#pragma unroll
-            for (int e0 = 0; e0 < NP; e0 += 4) {
-                // (this step's scalars have arrived -- the step before waited for everything -- but the compiler does not see waits inside
-                // the hand-written steps: told here, it does not put its own wait BEHIND the next fetch)
-                if (SMEM) __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
-                if (e0 + 4 < NP) fetch(e0 + 4, nxt);
-                sm_step<R>(acc, mk, row_off0, cur.xo, cur.sv);
-                cur = nxt;
-            }
-        } else {
-            for (int e0 = 0; e0 < n_pairs; e0 += 4) {
-                if (SMEM) __builtin_amdgcn_s_waitcnt(0xc07f);
-                fetch(min(e0 + 4, 28), nxt); // (past the last pair: fetched, not used)
-                sm_step<R>(acc, mk, row_off0, cur.xo, cur.sv);
-                cur = nxt;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t row = (slice0 + r) * 64 + lane;
-            if (row < n_rows) y[row] = acc[r];
-            if (MODE == 1) {
-                if (own >= 0) wr[r] = *reinterpret_cast<const double *>(lds + 16 + ((size_t)own * 8 + (wv * R + r) * 64 + lane) * 8);
-                const double t = wave_sum(row < n_rows ? acc[r] * wr[r] : 0.0);
-                if (lane == 0) partials[slice0 + r] = t;
-            }
-        }
-        if (dbg && tid == 0) { dbg[(size_t)b * 4 + 3] = (long long)__builtin_readcyclecounter() - t_start; dbg[(size_t)b * 4] = t_start; }
-        if (b + 1 < b_end) __syncthreads(); // (the window is the next block's from here on)
-        cb = nb;
+    const long long t_start = dbg ? (long long)__builtin_readcyclecounter() : 0; // diagnostic stamps (BIS_SELLWIN_DEBUG): shader cycles
+    const int hw = hdr[(size_t)b * 64 + lane];
+    const int64_t slice0 = ((int64_t)b * 4 + wv) * R;
+    // pair `lane`: its value and where its column for the block's first row lies in LDS
+    double pv = 0.0;
+    int pxo = 0;
+    if (lane < n_pairs) {
+        pv = dict_g[lane];
+        pxo = blk_base32[(size_t)b * 32 + lane];
     }
+    uint32_t mk[R];
+    double wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (slice0 + r) * 64 + lane;
+        mk[r] = nt_codes ? __builtin_nontemporal_load(&masks[row]) : masks[row]; // (the array is padded to whole blocks)
+        wr[r] = 0.0;
+        if (MODE == 1 && !own_rank && row < n_rows) wr[r] = w[row];
+    }
+    int own = -1;
+    if (MODE == 1 && own_rank) {
+        own = own_rank[b];
+        if (own < 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int64_t row = (slice0 + r) * 64 + lane; if (row < n_rows) wr[r] = w[row]; }
+        }
+    }
+    { // the window: as in spmv_sellwin_kernel
+        const int n_runs = __popcll(__ballot(lane >= 32 && (hw >> 16) != 0));
+        if (dbg && tid == 0) dbg[(size_t)b * 4 + 1] = (long long)__builtin_readcyclecounter() - t_start; // header arrived
+        unsigned char *win = lds + 16;
+        for (int k = 0; k < n_runs; ++k) {
+            const int g0 = __builtin_amdgcn_readlane(hw, k);
+            const int w2 = __builtin_amdgcn_readlane(hw, 32 + k);
+            const int rank = w2 & 0xffff, n_pieces = (w2 >> 16) * 4;
+            const int j = (wv + k) & 3;
+            const int p = j * 64 + lane;
+            const int64_t c = (int64_t)g0 * 8 + 2 * p;
+            unsigned char *dst = win + (size_t)rank * 64 + (size_t)j * 1024;
+            if (p < n_pieces) {
+                if (x_al16 && c + 1 < n_cols) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + c),
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                } else {
+                    double2 v;
+                    v.x = c < n_cols ? x[c] : 0.0;
+                    v.y = c + 1 < n_cols ? x[c + 1] : 0.0;
+                    *reinterpret_cast<double2 *>(dst + lane * 16) = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (dbg && tid == 0) dbg[(size_t)b * 4 + 2] = (long long)__builtin_readcyclecounter() - t_start; // window arrived, barrier passed
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    const unsigned row_off0 = (unsigned)((wv * R * 64 + lane) * 8); // (the wave's slice r: + 512 r)
+    const unsigned pv_lo = (unsigned)(unsigned long long)__double_as_longlong(pv), pv_hi = (unsigned)((unsigned long long)__double_as_longlong(pv) >> 32);
+    auto step = [&](int e0) { // pairs e0 .. e0 + 3 (no row has the ones past the last)
+        unsigned xo[4];
+        double sv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = min(e0 + q, 31);
+            xo[q] = (unsigned)__builtin_amdgcn_readlane(pxo, e);
+            sv[q] = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)pv_hi, e) << 32) |
+                                                     (unsigned)__builtin_amdgcn_readlane((int)pv_lo, e)));
+        }
+        sm_step<R>(acc, mk, row_off0, xo, sv);
+    };
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int e0 = 0; e0 < NP; e0 += 4) step(e0);
+    } else {
+        for (int e0 = 0; e0 < n_pairs; e0 += 4) step(e0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (slice0 + r) * 64 + lane;
+        if (row < n_rows) y[row] = acc[r];
+        if (MODE == 1) {
+            if (own >= 0) wr[r] = *reinterpret_cast<const double *>(lds + 16 + ((size_t)own * 8 + (wv * R + r) * 64 + lane) * 8);
+            const double t = wave_sum(row < n_rows ? acc[r] * wr[r] : 0.0);
+            if (lane == 0) partials[slice0 + r] = t;
+        }
+    }
+    if (dbg && tid == 0) { dbg[(size_t)b * 4 + 3] = (long long)__builtin_readcyclecounter() - t_start; dbg[(size_t)b * 4] = t_start; }
 }
 
 // (Measured and removed: a "chained" variant of the fmt 3 kernel in which one workgroup walks 2 / 4 / 8 consecutive blocks and
@@ -902,7 +878,6 @@ __global__ __launch_bounds__(64 * WAVES) void spmv_sellmask_kernel(
 // leaves three workgroups = three waves per SIMD, and the computation -- two dependent LDS round trips per four non-zeros
 // -- needs the six waves per SIMD of the single-buffer kernel to cover its own LDS latency.)
 bool sw_enabled() { return bis_opts().spmv_sellwin != 0; }
-int sw_mask_chain() { const int c = bis_opts().spmv_sellwin_chain; return c > 0 ? std::min(c, 64) : 1; } // fmt 4: blocks a workgroup walks (measured: 1 / 2 / 4 / 8 -> 0.118 / 0.115 / 0.123 / 0.125 ms at HPCG-256 -- hiding the header trip buys nothing, the kernel is not latency-bound)
 
 } // namespace
 
@@ -1154,11 +1129,7 @@ static bis_status sw_try_rows(bis_ctx *ctx, bis_mat *A, int R) {
     return BIS_OK;
 }
 
-// launch units: blocks, or (fmt 4) workgroups that walk sw_mask_chain() blocks each
-int bis_spmv_sellwin_blocks(const bis_mat *A) {
-    if (A->sw_state != 1) return 0;
-    return A->sw->fmt == 4 ? (A->sw->n_blocks + sw_mask_chain() - 1) / sw_mask_chain() : A->sw->n_blocks;
-}
+int bis_spmv_sellwin_blocks(const bis_mat *A) { return A->sw_state == 1 ? A->sw->n_blocks : 0; }
 int64_t bis_spmv_sellwin_slices(const bis_mat *A) { return A->sw_state == 1 ? A->sw->n_slices : 0; }
 int bis_spmv_sellwin_format(const bis_mat *A) { return A->sw_state == 1 ? A->sw->fmt : -1; }
 
@@ -1189,11 +1160,10 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
     }
     const int32_t *own = (mode == 1 && w == x + A->view_row0 && x_al16) ? sw->own_rank : nullptr; // the fused dot's w is x itself (CG: p)
     if (sw->fmt == 4) {
-#define SM_L4(MODE, RR, NN, SM, WV)                                                                                        \
-    hipLaunchKernelGGL((spmv_sellmask_kernel<MODE, RR, NN, SM, WV>), dim3(grid), dim3(64 * WV), win, ctx->stream, x, y, A->n_rows, A->n_cols, \
+#define SM_L3(MODE, RR, NN)                                                                                                \
+    hipLaunchKernelGGL((spmv_sellmask_kernel<MODE, RR, NN>), dim3(grid), dim3(256), win, ctx->stream, x, y, A->n_rows, A->n_cols, \
                        sw->n_blocks, remap_arg, w, partials, stop, sw->hdr, sw->codes, sw->dict, x_al16 | (bis_opts().spmv_sellwin_nt != 0 ? 2 : 0), \
-                       (const int32_t *)sw->blk_base, sw->n_pairs, own, sw_mask_chain(), dbg)
-#define SM_L3(MODE, RR, NN) do { if (bis_opts().spmv_sellwin_smem > 0) SM_L4(MODE, RR, NN, true, 4); else SM_L4(MODE, RR, NN, false, 4); } while (0)
+                       (const int32_t *)sw->blk_base, sw->n_pairs, own, dbg)
 #define SM_L2(MODE) do {                                                                                                   \
         if (sw->R == 4 && sw->n_pairs == 27) SM_L3(MODE, 4, 27);                                                           \
         else if (sw->R == 4) SM_L3(MODE, 4, 0);                                                                            \
@@ -1202,7 +1172,6 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
         if (mode == 1) SM_L2(1); else SM_L2(0);
 #undef SM_L2
 #undef SM_L3
-#undef SM_L4
     } else {
 #define SW_L4(MODE, DIAG, FMT, RR)                                                                                     \
     hipLaunchKernelGGL((spmv_sellwin_kernel<MODE, DIAG, FMT, RR>), dim3(grid), dim3(256), (FMT == 3 ? win_off3 : (size_t)(SwLayout<DIAG, FMT, RR>::kWinOff)) + win, \

@@ -13,7 +13,7 @@ lib = load_library()
 ctx = Context(0)
 ref = None
 for c in cfgs:
-    for k in ("masks", "pairs", "joint", "rows", "nt", "smem", "chain"):
+    for k in ("masks", "pairs", "joint", "rows", "nt"):
         lib.bis_set_option(("spmv_sellwin_" + k).encode(), int(c.get(k, -1)))
     A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_anderson(n1, shift=9.0)
     N = A.n_rows
