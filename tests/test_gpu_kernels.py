@@ -376,6 +376,19 @@ def hpcg_full_size_properties(ctx, n1, cg_iters):
     ctx.sum_vectors(ones, yu, yv, -0.75)
     ctx.subtract_vectors(ones, ones, y, 1.0)
     assert ctx.euclidean_vec_norm(ones) <= 1e-13 * 52 * np.sqrt(N)
+    # the library's default stream format for this matrix (round 4: 32 bits per row, the row-mask kernel) against the kernel that
+    # streams the CRS value array, on a second copy of the operator: y bit for bit
+    assert dA.spmv_stream_info()[:2] == (0, 0) and dA.spmv_stream_info()[3] == 4
+    ctx.set_option("spmv_valdict", 0)
+    try:
+        dB = ctx.gen_hpcg(n1)
+        ctx.spmv(dB, du, y)
+        assert dB.spmv_stream_info()[1:] == (8, 0, 0)
+    finally:
+        ctx.set_option("spmv_valdict", -1)
+    ctx.subtract_vectors(y, y, yu, 1.0)
+    assert ctx.euclidean_vec_norm(y) == 0.0
+    dB.free()
     # symmetry: (Au, v) == (u, Av)
     a, b2 = ctx.dot(yu, dv), ctx.dot(du, yv)
     assert abs(a - b2) <= 1e-12 * max(abs(a), 1.0) * 10
