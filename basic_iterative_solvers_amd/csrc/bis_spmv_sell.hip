@@ -71,7 +71,7 @@ constexpr int kSwMaxGran = 940; // window <= (2 + 8 * 940) * 8 = 60176 bytes (li
 constexpr int kSwDefaultR = 2;
 constexpr int kSwMaxPairs = 253; // fmt 3: pairs of a matrix at most (the padding takes the next index)
 // ... and with the tables in front of it the workgroup stays within 64 KiB of LDS
-inline int sw_gran_cap(int R) { return std::min(kSwMaxGran, (65536 - (4096 + 4096 * R) - 16) / 64); } // (the largest table area: fmt 3 with per-row diagonals)
+inline int sw_gran_cap(int R) { return R == 4 ? kSwMaxGran : std::min(kSwMaxGran, (65536 - (4096 + 4096 * R) - 16) / 64); } // (the largest table area: fmt 3 with per-row diagonals; R = 4 is the row-mask form only: no tables)
 
 // a (column - row, value code) pair as one key: ascending keys = ascending (signed) offsets, so a row with ascending columns runs
 // through the sorted list front to back
