@@ -1415,6 +1415,84 @@ def test_spmv_sellwin_form_is_bit_identical(ctx, oracle, rp64, rows, joint, pair
         ctx.set_option("spmv_sellwin_masks", -1)
 
 
+def _pair_matrix(rng, n, offsets, values, p_keep, sort=True, dup=False, empty_every=37):
+    """Row r has the entries {(r + offsets[e], values[e]) : e kept with probability p_keep, column inside the matrix} -- at most
+    len(offsets) distinct (column - row, value) pairs in the whole matrix; ascending columns unless sort is False; dup: some rows
+    hold one of their entries twice."""
+    offsets, values = np.asarray(offsets), np.asarray(values, dtype=np.float64)
+    order = np.argsort(offsets, kind="stable")
+    offsets, values = offsets[order], values[order]
+    cols, vals, lens = [], [], []
+    for r in range(n):
+        keep = (rng.uniform(size=len(offsets)) < p_keep) & (r + offsets >= 0) & (r + offsets < n)
+        if empty_every and r % empty_every == 5:
+            keep[:] = False
+        c, v = (r + offsets[keep]).astype(np.int32), values[keep]
+        if dup and len(c) and r % 11 == 3:
+            c, v = np.concatenate([c, c[-1:]]), np.concatenate([v, v[-1:]])
+        if not sort and len(c) > 1 and r % 7 == 2:
+            c, v = c[::-1], v[::-1]
+        cols.append(c); vals.append(v); lens.append(len(c))
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    return CRS(n, rp, np.concatenate(cols).astype(np.int32), np.concatenate(vals))
+
+
+@pytest.mark.parametrize("rp64,rows", [(0, 1), (1, 2), (0, 4)])
+def test_spmv_row_mask_form_randomised(ctx, oracle, rp64, rows):
+    """The row-mask form (bis_spmv_sell.hip, spmv_sellmask_kernel: 32 bits per row over the matrix' <= 32 (column - row, value)
+    pairs) on matrices that are NOT stencils of a grid: rows with random subsets of the pairs, empty rows, 1 .. 32 pairs (pair
+    counts that are no multiple of the four pairs a step takes), two pairs with the same offset and different values, values
+    -0.0 / denormal / huge / infinite; x with infinities and NaNs -- an entry a row does not have must not touch its sum
+    (0 * inf), an entry it has must, exactly as in the CRS kernel.  y bit-identical to the kernel that streams the CRS
+    values.  33 pairs, rows with descending columns, a column twice in a row: the form must not be chosen (the byte codes or
+    the gather kernels run, same y)."""
+    rng = np.random.default_rng(700 + rp64 + rows)
+    ctx.set_option("force_rp64", rp64)
+    ctx.set_option("spmv_sellwin_rows", rows)
+    try:
+        offs32 = np.concatenate([np.arange(-8, 8), 300 + np.arange(8), -300 - np.arange(8)])
+        vals32 = np.array([26.0, -1.0, -0.0, 5e-324, 1.7976931348623157e308, -2.5, np.inf, 3.0])[rng.integers(0, 8, 32)]
+        cases = [("1 pair", _pair_matrix(rng, 3000, [0], [2.0], 1.0), True),
+                 ("3 pairs", _pair_matrix(rng, 5000, [-1, 0, 1], [-1.0, 4.0, -1.0], 0.9), True),
+                 ("6 pairs, two per offset", _pair_matrix(rng, 4000, [-2, -2, 0, 0, 5, 5], [1.0, 2.0, 3.0, 4.0, 5.0, 6.0], 0.5), True),
+                 ("27 pairs", _pair_matrix(rng, 9001, offs32[:27], vals32[:27], 0.8), True),
+                 ("32 pairs", _pair_matrix(rng, 20011, offs32, vals32, 0.7), True),
+                 ("32 pairs, sparse rows", _pair_matrix(rng, 6000, offs32, vals32, 0.15), None),  # (mostly padding: any form)
+                 ("33 pairs", _pair_matrix(rng, 6000, np.concatenate([offs32, [600]]), np.concatenate([vals32, [7.0]]), 0.8), False),
+                 ("descending rows", _pair_matrix(rng, 6000, offs32[:9], vals32[:9], 0.9, sort=False), False),
+                 ("a column twice", _pair_matrix(rng, 6000, offs32[:9], vals32[:9], 0.9, dup=True), False)]
+        for name, A, want_masks in cases:
+            x = rng.uniform(-1, 1, A.n_cols)
+            x[rng.integers(0, A.n_cols, 40)] = np.inf
+            x[rng.integers(0, A.n_cols, 40)] = np.nan
+            x[rng.integers(0, A.n_cols, 40)] = -0.0
+            ys = {}
+            for mode in (0, -1):
+                ctx.set_option("spmv_valdict", mode)
+                dA = ctx.matrix(A)
+                dx, dy = ctx.upload(x), ctx.alloc(A.n_rows)
+                ctx.init_vector(dy, 7.0)
+                ctx.spmv(dA, dx, dy)
+                ys[mode] = dy.to_host()
+                if mode == -1:
+                    info = dA.spmv_stream_info()
+                    if want_masks is True:
+                        assert info[:2] == (0, 0) and info[3] == 4, (name, info)
+                    elif want_masks is False:
+                        assert info[:2] != (0, 0), (name, info)
+                dA.free(); dx.free(); dy.free()
+            # (bit for bit where the sum is a number or an infinity; a NaN where the CRS kernel has a NaN -- which of two NaN operands
+            # an addition hands on, and with it the NaN's sign, depends on the operand order of the instruction, not on the arithmetic)
+            nan0, nan1 = np.isnan(ys[0]), np.isnan(ys[-1])
+            assert np.array_equal(nan0, nan1), name
+            assert np.array_equal(ys[0].view(np.uint64)[~nan0], ys[-1].view(np.uint64)[~nan0]), name
+            assert nan0.any() and np.isinf(ys[0]).any(), name  # (the case does exercise them)
+    finally:
+        ctx.set_option("spmv_valdict", -1)
+        ctx.set_option("force_rp64", -1)
+        ctx.set_option("spmv_sellwin_rows", -1)
+
+
 @pytest.mark.parametrize("rows,masks", [(1, -1), (2, -1), (4, -1), (2, 0)])
 def test_spmv_sellwin_in_fused_cg(ctx, oracle, rows, masks):
     """The fused (Ap, p) epilogue of form 4 sums over the same 256-row blocks and waves as the lane-per-row gather
