@@ -519,7 +519,9 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     if (n == 0) return BIS_OK;
     // natural orderings on a grid: the tiled sweep (modes: bis_trsv_tiled_build), tried first -- its plan
     // checks the dependency order itself, so where it applies the level analysis below is never made
-    if (bis_opts().trsv_tiled != 0 && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_one_xcd <= 0) {
+    const bool tiled_allowed = bis_opts().trsv_tiled != 0 && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_one_xcd <= 0;
+    auto tiled_sweep = [&](bool *done) -> bis_status {
+        *done = false;
         bis_mat *M = const_cast<bis_mat *>(T);
         bis_trsv_tiled *&ts = backward ? M->tiled_bwd : M->tiled_fwd;
         bool &tried = backward ? M->tiled_tried_bwd : M->tiled_tried_fwd;
@@ -528,7 +530,20 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
             const bis_status tst = bis_trsv_tiled_build(ctx, T, backward, &ts);
             if (tst != BIS_OK) return tst;
         }
-        if (ts) return bis_trsv_tiled_solve(ctx, ts, x, D, b);
+        if (!ts) return BIS_OK;
+        *done = true;
+        return bis_trsv_tiled_solve(ctx, ts, x, D, b);
+    };
+    // ... except on grids with several unknowns per node and up to ~a million rows, where the chained sweep is tried first: the
+    // unknowns of a node are a chain, the tiles of such a matrix are 2 x 2 x 2 nodes, and the chained sweep measured faster
+    // (FEM-like 20^3 / 40^3 / 60^3 x 3: 0.40 / 0.84 / 1.42 ms against 0.53 / 1.05 / 1.63 tiled; 80^3 x 3 a tie at 2.3; 100^3 x 3
+    // 4.8 / 6.4 against 3.0 -- there the wavefront is wider than the resident wave pairs).  The tiled sweep stays the fall-back.
+    const bool chain_first = tiled_allowed && bis_opts().trsv_tiled < 0 && bis_opts().trsv_chain < 0 && T->grid[0] > 0 && T->grid[3] > 1 &&
+                             n >= 16384 && n <= 1200000;
+    if (tiled_allowed && !chain_first) {
+        bool done = false;
+        const bis_status tst = tiled_sweep(&done);
+        if (tst != BIS_OK || done) return tst;
     }
     bis_trsv_plan *p = nullptr;
     bis_status st = get_plan(ctx, T, backward, &p);
@@ -573,6 +588,11 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
             p->level = nullptr;
         }
         if (cs) return bis_trsv_chain_solve(ctx, T, cs, x, D, b);
+    }
+    if (chain_first) { // (no chained plan for this matrix after all)
+        bool done = false;
+        const bis_status tst = tiled_sweep(&done);
+        if (tst != BIS_OK || done) return tst;
     }
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,

@@ -228,3 +228,35 @@ def test_chained_sweep_randomised_bit_exact(ctx, oracle, capfd, monkeypatch, see
         ctx.set_option("trsv_chain", -1)
         ctx.set_option("force_rp64", -1)
     dL.free(); dU.free()
+
+
+def test_multi_dof_grid_takes_the_chained_sweep_first(ctx, oracle, capfd, monkeypatch):
+    """A grid-hinted matrix with several unknowns per node and 16 k .. 1.2 M rows (the FEM-like generator at 20 x 20 x 21 nodes):
+    the chained sweep is tried before the tiled one (bis_sptrsv.hip, trsv_solve) -- bit-exact against the oracle either way, the
+    plan lines say which ran; `trsv_tiled 1` asks for the tiled sweep explicitly; a small grid (7 x 6 x 5 nodes) stays tiled."""
+    monkeypatch.setenv("BIS_TRSV_CHAIN_STATS", "1")
+    monkeypatch.setenv("BIS_TRSV_TILE_STATS", "1")
+    for shape, tiled_opt, want in (((20, 20, 21), -1, "chained"), ((20, 20, 21), 1, "tiled"), ((7, 6, 5), -1, "tiled")):
+        A = oracle.gen_fem(*shape)
+        n = A.n_rows
+        L, Ls, U, Us = oracle.split_LU(A)
+        D, _, _ = oracle.peel_diag(L)
+        b = np.random.default_rng(23).uniform(-1, 1, n)
+        ctx.set_option("trsv_tiled", tiled_opt)
+        try:
+            dLs, dUs, dD, dDinv = ctx.split_strict(ctx.gen_fem(*shape))
+            db, x = ctx.upload(b), ctx.alloc(n)
+            capfd.readouterr()
+            for _ in range(2):
+                ctx.sptrsv(dLs, x, dD, db)
+                assert np.array_equal(x.to_host(), oracle.sptrsv(Ls, D, b))
+                ctx.bsptrsv(dUs, x, dD, db)
+                assert np.array_equal(x.to_host(), oracle.sptrsv(Us, D, b, backward=True))
+            ctx.sync()
+            err = capfd.readouterr().err
+            if want == "chained":
+                assert err.count("chained sptrsv plan") == 2 and "NOT used" not in err and "tiled sptrsv plan" not in err, err
+            else:
+                assert err.count("tiled sptrsv plan") == 2 and "chained sptrsv plan" not in err, err
+        finally:
+            ctx.set_option("trsv_tiled", -1)
