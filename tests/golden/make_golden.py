@@ -202,9 +202,12 @@ R4_RUNS = [
     ("anderson32_raw", "anderson:32", lambda o: o.gen_anderson(32), [("cg", "none", dict(max_iters=100)),
                                                                       ("cg", "j", dict(max_iters=100))]),
     ("unstr_12x11x10", "unstr:12,11,10", lambda o: o.gen_unstr(12, 11, 10),
-     [("bi", "ilu0", dict(ilu_real=True)), ("gm", "gs", dict(restart_len=50)), ("cg", "sgs", {}), ("gs", "none", {})]),
+     [("bi", "ilu0", dict(ilu_real=True)), ("gm", "gs", dict(restart_len=50)), ("cg", "sgs", {}), ("gs", "none", {}),
+      # (added later in round 4: the other solver / preconditioner pairs on the matrix without a grid)
+      ("gm", "ilu0", dict(ilu_real=True, restart_len=50)), ("cg", "ilu0", dict(ilu_real=True)), ("bi", "sgs", {}), ("cg", "j", {}),
+      ("sgs", "none", {}), ("bi", "2st", {}), ("gm", "s2st", dict(restart_len=50))]),
     ("unstr_20x20x20", "unstr:20,20,20", lambda o: o.gen_unstr(20, 20, 20),
-     [("bi", "ilu0", dict(ilu_real=True)), ("gm", "gs", dict(restart_len=50))]),
+     [("bi", "ilu0", dict(ilu_real=True)), ("gm", "gs", dict(restart_len=50)), ("cg", "sgs", {}), ("gm", "ilu0", dict(ilu_real=True, restart_len=50))]),
 ]
 
 
