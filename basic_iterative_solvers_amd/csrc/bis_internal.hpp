@@ -333,6 +333,7 @@ bis_status bis_trsv_chain_build(bis_ctx *ctx, const bis_mat *T, bool backward, c
                                 bis_trsv_chain **out);
 bis_status bis_trsv_chain_solve(bis_ctx *ctx, const bis_mat *T, bis_trsv_chain *p, double *x, const double *D, const double *b);
 void bis_trsv_chain_destroy(bis_trsv_chain *p);
+int bis_trsv_chain_resident_pairs(const bis_ctx *ctx, bool rp64, bool backward); // wave pairs (= chains in flight) of a full grid
 // contiguous independent row blocks of a strictly triangular matrix, in processing order (bis_analysis.hip)
 bis_status bis_trsv_blocks_device(bis_ctx *ctx, const bis_mat *T, bool backward, int max_blocks,
                                   std::vector<int64_t> &bounds, int32_t *perm_dev, bool &triangular);

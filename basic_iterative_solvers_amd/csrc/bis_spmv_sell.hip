@@ -735,6 +735,10 @@ __global__ __launch_bounds__(256) void spmv_sellwin_kernel(
                       [m##r##0] "=&s"(m[r][0]), [m##r##1] "=&s"(m[r][1]), [m##r##2] "=&s"(m[r][2]), [m##r##3] "=&s"(m[r][3])
 #define SM_OUT_A [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [a3] "=&v"(a[3])
 #define SM_IN [roff] "v"(roff), [xo0] "s"(xo[0]), [xo1] "s"(xo[1]), [xo2] "s"(xo[2]), [xo3] "s"(xo[3]), [v0] "s"(sv[0]), [v1] "s"(sv[1]), [v2] "s"(sv[2]), [v3] "s"(sv[3])
+// PRECONDITION: exec is all ones on entry (the block rewrites exec and leaves it all ones: SM_END).  Every call site sits in
+// wave-uniform control flow -- the pair loop's bounds and the block's row count are scalar -- and a kernel is entered with a full
+// execution mask (256-thread workgroups).  hipcc rejects exec on a clobber list ("reserved register"), so the rule is this
+// comment: never call sm_step under a lane-dependent branch.
 template <int R>
 __device__ __forceinline__ void sm_step(double (&acc)[R], uint32_t (&mk)[R], unsigned roff, const unsigned (&xo)[4], const double (&sv)[4]) {
     unsigned a[4];
@@ -904,10 +908,12 @@ void bis_spmv_sellwin_drop(bis_mat *A) {
         }                                                                      \
     } while (0)
 
-// fmt 3 on top of a finished plan (A->sw: runs, slices, chunk offsets).  Leaves A->sw_state == 1 on success; on "does not
-// apply" everything it allocated is freed and the caller goes on with another format; an out-of-memory drops the form.
-static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, int pad_idx) {
-    bis_sellwin *sw = A->sw;
+// The distinct (column - row, value code) pairs of the matrix, sorted; `known` says the list has been made, `fits` that there are
+// 1 .. kSwMaxPairs of them.  Made once per build (the list depends on the matrix only, not on the block size of the plan).
+struct SwPairs { bool known = false, fits = false; std::vector<unsigned long long> all; };
+
+static bis_status sw_collect_pairs(bis_ctx *ctx, bis_mat *A, SwPairs &P) {
+    P.known = true; P.fits = false; P.all.clear();
     int32_t *slice_chunks = nullptr; // (SW_CHECK's clean-up names)
     void *tmp = nullptr;
     const int n_waves = (int)std::min<int64_t>((A->n_rows + 63) / 64, (int64_t)ctx->n_cus * 8);
@@ -926,15 +932,29 @@ static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, in
     SW_CHECK(hipStreamSynchronize(ctx->stream));
     hipFree(lists); tmp = nullptr;
     if (over) return BIS_OK;
-    std::vector<unsigned long long> all;
+    std::vector<unsigned long long> &all = P.all;
     for (int w = 0; w < n_waves; ++w) {
         const size_t n = (size_t)h[(size_t)w * 257];
-        if (n > (size_t)kSwMaxPairs) return BIS_OK;
+        if (n > (size_t)kSwMaxPairs) { all.clear(); return BIS_OK; }
         all.insert(all.end(), h.begin() + (size_t)w * 257 + 1, h.begin() + (size_t)w * 257 + 1 + n);
     }
     std::sort(all.begin(), all.end());
     all.erase(std::unique(all.begin(), all.end()), all.end());
-    if (all.empty() || all.size() > (size_t)kSwMaxPairs) return BIS_OK;
+    P.fits = !all.empty() && all.size() <= (size_t)kSwMaxPairs;
+    return BIS_OK;
+}
+
+// fmt 3 on top of a finished plan (A->sw: runs, slices, chunk offsets).  Leaves A->sw_state == 1 on success; on "does not
+// apply" everything it allocated is freed and the caller goes on with another format; an out-of-memory drops the form.
+static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, int pad_idx, SwPairs &P) {
+    bis_sellwin *sw = A->sw;
+    int *status = (int *)ctx->counters + 52;
+    if (!P.known) {
+        if (bis_status st = sw_collect_pairs(ctx, A, P)) return st;
+        if (!A->sw) return BIS_OK; // (dropped on an allocation failure)
+    }
+    if (!P.fits) return BIS_OK;
+    const std::vector<unsigned long long> &all = P.all;
     const int n_pairs = (int)all.size();
     unsigned long long keys[256];
     double vals[256];
@@ -1006,7 +1026,7 @@ static bis_status sw_try_pairs(bis_ctx *ctx, bis_mat *A, const double *table, in
 }
 
 // Build the form for a matrix that has a value dictionary (A->vd_state == 1); A->sw_state tells the outcome.
-static bis_status sw_try_rows(bis_ctx *ctx, bis_mat *A, int R);
+static bis_status sw_try_rows(bis_ctx *ctx, bis_mat *A, int R, SwPairs &P);
 
 bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     if (A->sw_state != 0) return BIS_OK;
@@ -1021,15 +1041,21 @@ bis_status bis_spmv_sellwin_try(bis_ctx *ctx, bis_mat *A) {
     }
     // Blocks of 1024 rows exist for the row-mask form only (its waves keep 4 x 4 LDS reads in flight: HPCG-256 0.116 against 0.125 ms
     // with 512 rows): tried first where that form can apply, and the plan is redone with 512 rows where it then does not.
+    // The pairs are counted BEFORE that plan is made (one light pass over the matrix): a matrix with more than 32 of them goes to
+    // the 512-row plan directly instead of building the 1024-row plan and its tables only to drop them.
+    SwPairs P;
     if (big && !A->vd_diag && bis_opts().spmv_sellwin_masks != 0 && bis_opts().spmv_sellwin_pairs != 0) {
-        if (bis_status st = sw_try_rows(ctx, A, 4)) return st;
-        if (A->sw_state == 1) return BIS_OK;
-        A->sw_state = -1;
+        if (bis_status st = sw_collect_pairs(ctx, A, P)) return st;
+        if (P.fits && P.all.size() <= 32) {
+            if (bis_status st = sw_try_rows(ctx, A, 4, P)) return st;
+            if (A->sw_state == 1) return BIS_OK;
+            A->sw_state = -1;
+        }
     }
-    return sw_try_rows(ctx, A, R);
+    return sw_try_rows(ctx, A, R, P);
 }
 
-static bis_status sw_try_rows(bis_ctx *ctx, bis_mat *A, int R) {
+static bis_status sw_try_rows(bis_ctx *ctx, bis_mat *A, int R, SwPairs &P) {
     const int64_t nb64 = (A->n_rows + (int64_t)kSwRows * R - 1) / ((int64_t)kSwRows * R);
     if (nb64 > (int64_t)1 << 26) return BIS_OK;
     const int nb = (int)nb64;
@@ -1109,7 +1135,7 @@ static bis_status sw_try_rows(bis_ctx *ctx, bis_mat *A, int R) {
     // fmt 3 first: one byte per non-zero where the matrix has few (column - row, value) pairs that run through every
     // block's window in step with the rows
     if (bis_opts().spmv_sellwin_pairs != 0) {
-        if (bis_status st = sw_try_pairs(ctx, A, table, pad_idx)) return st;
+        if (bis_status st = sw_try_pairs(ctx, A, table, pad_idx, P)) return st;
         if (A->sw && sw->R == 4 && !(A->sw_state == 1 && sw->fmt == 4)) { // (blocks of 1024 rows exist for the row-mask form only)
             bis_spmv_sellwin_drop(A);
             A->sw_state = -1;

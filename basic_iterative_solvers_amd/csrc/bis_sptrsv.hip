@@ -36,6 +36,7 @@
 #include "bis_internal.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 struct bis_trsv_plan {
@@ -420,7 +421,8 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
     bis_trsv_plan *p = new bis_trsv_plan;
     p->n = n;
     hipError_t e = hipMalloc(&p->perm, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1));
-    if (e == hipSuccess) e = hipMalloc(&p->xs, sizeof(double) * (size_t)(n + 1)); // + one slot nobody publishes (test hook)
+    // (xs, the level-scheduled kernels' scratch, is allocated at their first sweep: a matrix that ends up on the chained or the
+    // tiled sweep never needs it)
     if (e == hipSuccess) e = hipMalloc(&p->ticket, sizeof(unsigned) * 4);
     if (e != hipSuccess) {
         ctx->err = std::string("sptrsv plan: ") + hipGetErrorString(e);
@@ -538,8 +540,12 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     // unknowns of a node are a chain, the tiles of such a matrix are 2 x 2 x 2 nodes, and the chained sweep measured faster
     // (FEM-like 20^3 / 40^3 / 60^3 x 3: 0.40 / 0.84 / 1.42 ms against 0.53 / 1.05 / 1.63 tiled; 80^3 x 3 a tie at 2.3; 100^3 x 3
     // 4.8 / 6.4 against 3.0 -- there the wavefront is wider than the resident wave pairs).  The tiled sweep stays the fall-back.
+    // The upper bound scales with the wave pairs the device keeps resident for this context: the wavefront of a grid of n rows is
+    // ~n^(2/3) rows wide, so the rows a given number of pairs can follow grow with pairs^(3/2) (1.2 M rows measured at 2560 pairs).
+    const double pairs_rel = (double)bis_trsv_chain_resident_pairs(ctx, T->rp64 != 0, backward) / 2560.0;
+    const int64_t chain_first_max = (int64_t)(1200000.0 * pairs_rel * std::sqrt(pairs_rel));
     const bool chain_first = tiled_allowed && bis_opts().trsv_tiled < 0 && bis_opts().trsv_chain < 0 && T->grid[0] > 0 && T->grid[3] > 1 &&
-                             n >= 16384 && n <= 1200000;
+                             n >= 16384 && n <= chain_first_max;
     if (tiled_allowed && !chain_first) {
         bool done = false;
         const bis_status tst = tiled_sweep(&done);
@@ -592,7 +598,17 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     if (chain_first) { // (no chained plan for this matrix after all)
         bool done = false;
         const bis_status tst = tiled_sweep(&done);
+        if (tst == BIS_OK && done) { // the tiled sweep serves this triangle from now on: the level plan made for the chained attempt goes
+            bis_mat *M = const_cast<bis_mat *>(T);
+            bis_trsv_plan *&slot = backward ? M->plan_bwd : M->plan_fwd;
+            bis_trsv_plan_destroy(slot);
+            slot = nullptr;
+        }
         if (tst != BIS_OK || done) return tst;
+    }
+    if (!p->xs) {
+        const hipError_t xe = hipMalloc(&p->xs, sizeof(double) * (size_t)(n + 1)); // + one slot nobody publishes (test hook)
+        if (xe != hipSuccess) { (void)hipGetLastError(); ctx->err = "sptrsv: out of memory for the scratch vector"; return BIS_ERR_HIP; }
     }
     const int fill_grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fill_sentinel_kernel, dim3(fill_grid), dim3(256), 0, ctx->stream,

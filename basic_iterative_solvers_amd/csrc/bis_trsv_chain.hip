@@ -494,6 +494,11 @@ __global__ __launch_bounds__(256, kBlocksPerCU) void trsv_chain_kernel(const Cha
                     }
                     done += 64;
                     ++slot;
+                    // a long row gives its slots back segment by segment (the sum so far is in a register): the feeder's space check
+                    // counts slots, and a row of more segments than the ring has slots -- or one whose last segment falls into the
+                    // feeder's next group -- would otherwise wait for a release that only its own last segment brings.  (The last
+                    // segment's release stays behind the publish below: rows of <= 64 entries run as before.)
+                    if (done < len && lane == 0) lds_release(&L.ctl[C_DONE], slot);
                 } while (done < len);
                 {   // optimistic look at the next row (valid if the watermark, read first, covers its slot)
                     const unsigned wmn = lds_acquire(&L.ctl[C_WM]);
@@ -623,6 +628,8 @@ int chain_grid(const bis_ctx *ctx, bool rp64, bool backward) {
 }
 
 } // namespace
+
+int bis_trsv_chain_resident_pairs(const bis_ctx *ctx, bool rp64, bool backward) { return chain_grid(ctx, rp64, backward) * 2; }
 
 // *out stays null (BIS_OK) where the chained sweep does not apply: short chains, or more chains straddling a level than
 // the resident waves can hold (see the header).  level_dev: the dependency levels of T's rows (bis_trsv_analyse_device).
