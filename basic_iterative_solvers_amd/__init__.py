@@ -36,6 +36,7 @@ def load_library():
         _lib = C.CDLL(LIB_PATH)
         _lib.bis_last_error.restype = C.c_char_p
         _lib.bis_ctx_stream.restype = C.c_void_p
+        _lib.bis_mat_sweep_kernel.restype = C.c_char_p
     return _lib
 
 
@@ -69,6 +70,15 @@ class Context:
     def set_option(self, name, value):
         if self.lib.bis_set_option(name.encode(), C.c_int(int(value))) != 0:
             raise BisError(f"bis_set_option: unknown option {name}")
+
+    def options(self):
+        """The options in effect (bis_options_describe): every option not at its default + the BIS_* variables found in the
+        environment at first use -- for bench / test records."""
+        import json
+        n = self.lib.bis_options_describe(None, C.c_int(0))
+        buf = C.create_string_buffer(n + 1)
+        self.lib.bis_options_describe(buf, C.c_int(n + 1))
+        return json.loads(buf.value.decode())
 
     def device_info(self):
         arch = C.create_string_buffer(64)
@@ -320,6 +330,13 @@ class Context:
         self.check(self.lib.bis_profile_read(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def profile_read_sweeps(self):
+        """(sweeps, summed ms) of the bis_sptrsv / bis_bsptrsv calls made while profiling was on (HIP events on the library's stream)."""
+        n = C.c_int64()
+        ms = C.c_double()
+        self.check(self.lib.bis_profile_read_sweeps(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
 
 class Vec:
     """A device vector: raw `double*` + length (what the reference passes as
@@ -378,6 +395,10 @@ class Mat:
         a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self.ctx.check(self.ctx.lib.bis_mat_debug_ptrs(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def sweep_kernel(self, backward=False):
+        """Name of the kernel the last forward / backward sweep on this triangle ran (bis_mat_sweep_kernel)."""
+        return self.ctx.lib.bis_mat_sweep_kernel(self.h, C.c_int(int(backward))).decode()
 
     def retune(self):
         """Rebuild everything derived from the CRS arrays (bis_mat_retune): required after writing values in place."""

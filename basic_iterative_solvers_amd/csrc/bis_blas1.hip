@@ -237,37 +237,28 @@ bis_status bis_fault_check(bis_ctx *ctx) {
     return BIS_ERR_SYNC;
 }
 
+// ---- options: ONE table drives the environment, bis_set_option and bis_options_describe ---------------------------
+// X(name): settable through bis_set_option("name", v) AND, at first use, the environment variable BIS_<NAME>;
+// Y(name): bis_set_option only (per-call tuning knobs and test hooks: nothing a stray environment should reach).
+#define BIS_OPTIONS_ENV(X) X(spmv_variant) X(spmv_window) X(spmv_chunk) X(spmv_chunk_fused) X(spmv_xcd_remap) X(trsv_grid) X(trsv_one_xcd) X(trsv_host_analysis) X(ilu0_wave) X(spmv_packed) X(spmv_packed32) X(spmv_valdict) X(spmv_sellwin) X(device_share) X(spmv_sellwin_rows) X(spmv_sellwin_joint) X(spmv_sellwin_pairs) X(spmv_sellwin_masks) X(grid_autodetect) X(tune_placement) X(cg_graph) X(force_rp64) X(trsv_tiled) X(trsv_chain) X(trsv_tile_rows) X(trsv_tile_wgs) X(trsv_tile_edge) X(trsv_tile_backoff)
+#define BIS_OPTIONS_API(Y) Y(trsv_batch) Y(trsv_wave) Y(ilu0_persistent) Y(trsv_by_pos) Y(spmv_lds_pad) Y(trsv_chain_idle) Y(trsv_chain_pause) Y(trsv_chain_pairs) Y(trsv_chain_prefix) Y(trsv_tile_exp) Y(cg_nt_x) Y(spmv_sellwin_nt) Y(dist_host_plan) Y(trsv_inject_loss) Y(trsv_inject_oom)
+
+namespace {
+std::string &opts_env_seen() { static std::string s; return s; } // "BIS_X=v BIS_Y=w": the variables found at first use
+std::string upper_env(const char *name) {
+    std::string e = "BIS_";
+    for (const char *c = name; *c; ++c) e += (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+    return e;
+}
+} // namespace
+
 bis_options &bis_opts() {
     static bis_options o = [] {
         bis_options v;
-        if (const char *e = getenv("BIS_SPMV_VARIANT")) v.spmv_variant = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_WINDOW")) v.spmv_window = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_CHUNK")) v.spmv_chunk = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_CHUNK_FUSED")) v.spmv_chunk_fused = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_XCD_REMAP")) v.spmv_xcd_remap = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_GRID")) v.trsv_grid = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_ONE_XCD")) v.trsv_one_xcd = atoi(e);
-        if (const char *e = getenv("BIS_ILU0_WAVE")) v.ilu0_wave = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_HOST_ANALYSIS")) v.trsv_host_analysis = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_PACKED")) v.spmv_packed = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_PACKED32")) v.spmv_packed32 = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_VALDICT")) v.spmv_valdict = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_SELLWIN")) v.spmv_sellwin = atoi(e);
-        if (const char *e = getenv("BIS_DEVICE_SHARE")) v.device_share = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_SELLWIN_ROWS")) v.spmv_sellwin_rows = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_SELLWIN_JOINT")) v.spmv_sellwin_joint = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_SELLWIN_PAIRS")) v.spmv_sellwin_pairs = atoi(e);
-        if (const char *e = getenv("BIS_SPMV_SELLWIN_MASKS")) v.spmv_sellwin_masks = atoi(e);
-        if (const char *e = getenv("BIS_GRID_AUTODETECT")) v.grid_autodetect = atoi(e);
-        if (const char *e = getenv("BIS_TUNE_PLACEMENT")) v.tune_placement = atoi(e);
-        if (const char *e = getenv("BIS_CG_GRAPH")) v.cg_graph = atoi(e);
-        if (const char *e = getenv("BIS_FORCE_RP64")) v.force_rp64 = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_TILED")) v.trsv_tiled = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_CHAIN")) v.trsv_chain = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_TILE_ROWS")) v.trsv_tile_rows = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_TILE_WGS")) v.trsv_tile_wgs = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_TILE_EDGE")) v.trsv_tile_edge = atoi(e);
-        if (const char *e = getenv("BIS_TRSV_TILE_BACKOFF")) v.trsv_tile_backoff = atoi(e);
+#define X(name) { const std::string en = upper_env(#name); if (const char *e = getenv(en.c_str())) { v.name = atoi(e); \
+                  std::string &seen = opts_env_seen(); if (!seen.empty()) seen += ' '; seen += en + "=" + e; } }
+        BIS_OPTIONS_ENV(X)
+#undef X
         return v;
     }();
     return o;
@@ -279,51 +270,30 @@ extern "C" {
 bis_status bis_set_option(const char *name, int value) {
     if (!name) return BIS_ERR_INVALID;
     bis_options &o = bis_opts();
-    if (!strcmp(name, "spmv_variant")) o.spmv_variant = value;
-    else if (!strcmp(name, "spmv_window")) o.spmv_window = value;
-    else if (!strcmp(name, "spmv_chunk")) o.spmv_chunk = value;
-    else if (!strcmp(name, "spmv_chunk_fused")) o.spmv_chunk_fused = value;
-    else if (!strcmp(name, "spmv_xcd_remap")) o.spmv_xcd_remap = value;
-    else if (!strcmp(name, "trsv_grid")) o.trsv_grid = value;
-    else if (!strcmp(name, "trsv_one_xcd")) o.trsv_one_xcd = value;
-    else if (!strcmp(name, "trsv_batch")) o.trsv_batch = value;
-    else if (!strcmp(name, "trsv_wave")) o.trsv_wave = value;
-    else if (!strcmp(name, "trsv_host_analysis")) o.trsv_host_analysis = value;
-    else if (!strcmp(name, "ilu0_wave")) o.ilu0_wave = value;
-    else if (!strcmp(name, "ilu0_persistent")) o.ilu0_persistent = value;
-    else if (!strcmp(name, "trsv_by_pos")) o.trsv_by_pos = value;
-    else if (!strcmp(name, "spmv_packed")) o.spmv_packed = value;
-    else if (!strcmp(name, "spmv_lds_pad")) o.spmv_lds_pad = value;
-    else if (!strcmp(name, "spmv_packed32")) o.spmv_packed32 = value;
-    else if (!strcmp(name, "spmv_valdict")) o.spmv_valdict = value;
-    else if (!strcmp(name, "spmv_sellwin")) o.spmv_sellwin = value;
-    else if (!strcmp(name, "device_share")) o.device_share = value;
-    else if (!strcmp(name, "spmv_sellwin_rows")) o.spmv_sellwin_rows = value;
-    else if (!strcmp(name, "spmv_sellwin_joint")) o.spmv_sellwin_joint = value;
-    else if (!strcmp(name, "spmv_sellwin_pairs")) o.spmv_sellwin_pairs = value;
-    else if (!strcmp(name, "spmv_sellwin_masks")) o.spmv_sellwin_masks = value;
-    else if (!strcmp(name, "grid_autodetect")) o.grid_autodetect = value;
-    else if (!strcmp(name, "tune_placement")) o.tune_placement = value;
-    else if (!strcmp(name, "cg_graph")) o.cg_graph = value;
-    else if (!strcmp(name, "force_rp64")) o.force_rp64 = value;
-    else if (!strcmp(name, "trsv_tiled")) o.trsv_tiled = value;
-    else if (!strcmp(name, "trsv_chain")) o.trsv_chain = value;
-    else if (!strcmp(name, "trsv_chain_idle")) o.trsv_chain_idle = value;
-    else if (!strcmp(name, "trsv_chain_pause")) o.trsv_chain_pause = value;
-    else if (!strcmp(name, "trsv_chain_pairs")) o.trsv_chain_pairs = value;
-    else if (!strcmp(name, "trsv_chain_prefix")) o.trsv_chain_prefix = value;
-    else if (!strcmp(name, "trsv_tile_rows")) o.trsv_tile_rows = value;
-    else if (!strcmp(name, "trsv_tile_wgs")) o.trsv_tile_wgs = value;
-    else if (!strcmp(name, "trsv_tile_edge")) o.trsv_tile_edge = value;
-    else if (!strcmp(name, "trsv_tile_exp")) o.trsv_tile_exp = value;
-    else if (!strcmp(name, "cg_nt_x")) o.cg_nt_x = value;
-    else if (!strcmp(name, "spmv_sellwin_nt")) o.spmv_sellwin_nt = value;
-    else if (!strcmp(name, "trsv_tile_backoff")) o.trsv_tile_backoff = value;
-    else if (!strcmp(name, "dist_host_plan")) o.dist_host_plan = value;
-    else if (!strcmp(name, "trsv_inject_loss")) o.trsv_inject_loss = value;
-    else if (!strcmp(name, "trsv_inject_oom")) o.trsv_inject_oom = value;
-    else return BIS_ERR_INVALID;
-    return BIS_OK;
+#define X(opt) if (!strcmp(name, #opt)) { o.opt = value; return BIS_OK; }
+    BIS_OPTIONS_ENV(X)
+    BIS_OPTIONS_API(X)
+#undef X
+    return BIS_ERR_INVALID;
+}
+
+// The options in effect, for bench / CLI records: a JSON object {"option": value, ..., "env": "BIS_X=v ..."} of every option
+// that is not at its default (-1) and the BIS_* variables this process found in its environment at first use.  Returns the
+// length needed (excluding the terminator); writes at most cap - 1 characters.
+int bis_options_describe(char *buf, int cap) {
+    const bis_options &o = bis_opts();
+    std::string s = "{";
+    bool first = true;
+#define X(opt) if (o.opt != -1) { if (!first) s += ", "; first = false; s += std::string("\"") + #opt + "\": " + std::to_string(o.opt); }
+    BIS_OPTIONS_ENV(X)
+    BIS_OPTIONS_API(X)
+#undef X
+    if (!first) s += ", ";
+    s += "\"env\": \"";
+    for (char c : opts_env_seen()) if (c != '"' && c != '\\' && (unsigned char)c >= 32) s += c;
+    s += "\"}";
+    if (buf && cap > 0) { const int n = std::min((int)s.size(), cap - 1); memcpy(buf, s.data(), (size_t)n); buf[n] = 0; }
+    return (int)s.size();
 }
 
 int bis_abi_version(void) { return 1; }
@@ -380,6 +350,7 @@ bis_status bis_ctx_destroy(bis_ctx *ctx) {
     BIS_CTX_OK(ctx);
     hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->prof_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto &p : ctx->prof_sweep_events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     hipFree(ctx->partials);
     hipFree(ctx->scalars_dev);
     hipHostFree(ctx->scalars_host);
@@ -674,6 +645,21 @@ bis_status bis_profile_read(bis_ctx *ctx, int64_t *spmv_launches, double *spmv_m
     if (spmv_launches) *spmv_launches = (int64_t)ctx->prof_used;
     if (spmv_ms) *spmv_ms = ms;
     ctx->prof_used = 0;
+    return BIS_OK;
+}
+
+bis_status bis_profile_read_sweeps(bis_ctx *ctx, int64_t *sweeps, double *sweep_ms) {
+    BIS_CTX_OK(ctx);
+    BIS_SYNC_CHECK(ctx);
+    double ms = 0.0;
+    for (size_t i = 0; i < ctx->prof_sweep_used; ++i) {
+        float t = 0.f;
+        BIS_HIP_CHECK(ctx, hipEventElapsedTime(&t, ctx->prof_sweep_events[i].first, ctx->prof_sweep_events[i].second));
+        ms += t;
+    }
+    if (sweeps) *sweeps = (int64_t)ctx->prof_sweep_used;
+    if (sweep_ms) *sweep_ms = ms;
+    ctx->prof_sweep_used = 0;
     return BIS_OK;
 }
 

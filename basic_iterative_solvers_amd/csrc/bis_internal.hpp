@@ -53,6 +53,8 @@ struct bis_ctx {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_sweep_events; // one pair per bis_sptrsv / bis_bsptrsv call
+    size_t prof_sweep_used = 0;
 };
 
 // Tuning knobs (bis_set_option / BIS_* environment variables at first use).
@@ -185,6 +187,7 @@ struct bis_mat {
     // the chained sweep's plans (bis_trsv_chain.hip), for matrices without a grid: built from the level analysis
     struct bis_trsv_chain *chain_fwd = nullptr, *chain_bwd = nullptr;
     bool chain_tried_fwd = false, chain_tried_bwd = false;
+    const char *sweep_kernel[2] = {"", ""}; // the kernel the last forward / backward sweep on this triangle ran (bis_mat_sweep_kernel)
 };
 
 #define BIS_HIP_CHECK(ctx, call)                                               \

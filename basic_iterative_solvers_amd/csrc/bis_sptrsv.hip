@@ -512,8 +512,8 @@ bis_status get_plan(bis_ctx *ctx, const bis_mat *T, bool backward, bis_trsv_plan
     return BIS_OK;
 }
 
-bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, const double *D,
-                      const double *b) {
+bis_status trsv_solve_impl(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, const double *D,
+                           const double *b, const char *&kernel) {
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, T && (T->n_rows == 0 || (x && D && b)), "sptrsv: bad arguments");
     BIS_REQUIRE(ctx, T->n_rows == T->n_cols, "sptrsv: square matrix required");
@@ -534,6 +534,7 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
         }
         if (!ts) return BIS_OK;
         *done = true;
+        kernel = "trsv_tiled_kernel";
         return bis_trsv_tiled_solve(ctx, ts, x, D, b);
     };
     // ... except on grids with several unknowns per node and up to ~a million rows, where the chained sweep is tried first: the
@@ -555,6 +556,7 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     bis_status st = get_plan(ctx, T, backward, &p);
     if (st != BIS_OK) return st;
     if (!p->level_views.empty()) {
+        kernel = "spmv_rowblock_kernel (triangular epilogue, a launch per independent row block)";
         for (int l = 0; l < p->n_levels; ++l) {
             const int64_t r0 = p->level_row0[l];
             st = bis_spmv_trsv_level(ctx, p->level_views[l], x, x + r0, b + r0, D + r0);
@@ -563,6 +565,7 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
         return BIS_OK;
     }
     if (p->n_levels <= kFewLevels) {
+        kernel = "trsv_level_kernel (a launch per level)";
         for (int l = 0; l < p->n_levels; ++l) {
             const int64_t lo = p->level_ptr[l], hi = p->level_ptr[l + 1];
             const int grid = (int)std::min<int64_t>((hi - lo + 255) / 256, (int64_t)ctx->n_cus * 32);
@@ -593,7 +596,7 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
             hipFree(p->level);
             p->level = nullptr;
         }
-        if (cs) return bis_trsv_chain_solve(ctx, T, cs, x, D, b);
+        if (cs) { kernel = "trsv_chain_kernel"; return bis_trsv_chain_solve(ctx, T, cs, x, D, b); }
     }
     if (chain_first) { // (no chained plan for this matrix after all)
         bool done = false;
@@ -709,8 +712,10 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
                                (const int32_t *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,
                                (unsigned long long *)p->xs, p->ticket, pos_flag, ctx->fault_dev, ctx->spmv_stop);
         BIS_HIP_CHECK(ctx, hipGetLastError());
+        kernel = "sptrsv_wave_kernel";
         return BIS_OK;
     }
+    kernel = "sptrsv_syncfree_kernel";
 #define BIS_TRSV_LAUNCH(RP, ONE, B)                                                                    \
     hipLaunchKernelGGL((sptrsv_syncfree_kernel<RP, ONE, B>), dim3(grid), dim3(kTrsvT), 0, ctx->stream, \
                        (const RP *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,                      \
@@ -730,6 +735,30 @@ bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, 
     return BIS_OK;
 }
 
+// one sweep = every launch of the call (sentinel fill + the sweep kernel, or a launch per level): HIP-event bracketed on the
+// context's stream while bis_profile_enable is on (bis_profile_read_sweeps)
+bis_status trsv_solve(bis_ctx *ctx, const bis_mat *T, bool backward, double *x, const double *D, const double *b) {
+    BIS_CTX_OK(ctx);
+    const bool prof = ctx->profile && T && T->n_rows > 0;
+    if (prof) {
+        if (ctx->prof_sweep_used == ctx->prof_sweep_events.size()) {
+            hipEvent_t a, e;
+            hipEventCreate(&a);
+            hipEventCreate(&e);
+            ctx->prof_sweep_events.emplace_back(a, e);
+        }
+        hipEventRecord(ctx->prof_sweep_events[ctx->prof_sweep_used].first, ctx->stream);
+    }
+    const char *kernel = "";
+    const bis_status st = trsv_solve_impl(ctx, T, backward, x, D, b, kernel);
+    if (prof) {
+        hipEventRecord(ctx->prof_sweep_events[ctx->prof_sweep_used].second, ctx->stream);
+        ++ctx->prof_sweep_used;
+    }
+    if (T && st == BIS_OK && kernel[0]) const_cast<bis_mat *>(T)->sweep_kernel[backward ? 1 : 0] = kernel;
+    return st;
+}
+
 } // namespace
 
 bis_status bis_trsv_level_sets(bis_ctx *ctx, const bis_mat *T_lower, const std::vector<int64_t> **level_ptr,
@@ -743,6 +772,8 @@ bis_status bis_trsv_level_sets(bis_ctx *ctx, const bis_mat *T_lower, const std::
 }
 
 extern "C" {
+
+const char *bis_mat_sweep_kernel(const bis_mat *T, int backward) { return T ? T->sweep_kernel[backward ? 1 : 0] : ""; }
 
 bis_status bis_sptrsv(bis_ctx *ctx, const bis_mat *L_strict, double *x, const double *D,
                       const double *b) {

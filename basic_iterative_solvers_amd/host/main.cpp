@@ -59,6 +59,12 @@ int main(int argc, char *argv[]) {
     if (cli_args.trsv_mode == 3) { bis_set_option("trsv_tiled", 0); bis_set_option("trsv_chain", 0); }
     TIME(&timers, "total", run(&cli_args, &timers))
     print_timers(&cli_args, &timers);
+    {   // one line BEHIND the reference's output: the library options in effect (bis_set_option state and the BIS_* variables
+        // found in the environment), so that a record of this run says which kernels it selected
+        char opts[2048];
+        bis_options_describe(opts, (int)sizeof opts);
+        std::cout << "Device library options in effect: " << opts << std::endl;
+    }
     bis::shutdown();
     return 0;
 }

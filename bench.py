@@ -26,6 +26,16 @@ a statement about CRS bandwidth); `target_512` = both at the north-star size,
 CG (oracle/_ref) on the host cores for a bounded number of iterations, and
 `parity_max_dr_over_r0` compares a GPU run of the same length with that history
 (N = 1, rank 0 only).
+
+The PRECONDITIONED half of the path (round 5): `sweeps` = forward / backward
+bis_sptrsv (native_sptrsv / native_bsptrsv, kernels.hpp:54-117) on HPCG-256,
+Anderson-256, fem:80,80,81 and unstr:80,80,80 (as generated and RCM-ordered),
+HIP-event timed on the library's stream, each with a roofline on 12 nnz_T + 28 N
+(SURVEY 8d), the kernel that ran and the PMC traffic of profiles/trsv_traffic.json;
+`cpu_baseline_sptrsv` = the reference's serial native_sptrsv on HPCG-128 beside
+it; `configs` = BASELINE configs 2, 4, 5 through the host CLI (the library's
+GMRES / BiCGSTAB schedules) with iterations, iterate time and the timer tree's
+SpMV / preconditioner / BLAS-1 split; `options` = the library options in effect.
 """
 import argparse
 import json
@@ -67,6 +77,8 @@ def parse():
     ap.add_argument("--tune-placement", type=int, default=0,
                     help="setup: keep the fastest of K re-allocations of the matrix' streamed arrays "
                          "(bis_mat_tune_placement; 0 = off)")
+    ap.add_argument("--no-sweeps", action="store_true", help="skip the `sweeps` legs (natural-order SpTRSV per workload)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` legs (BASELINE configs 2-5 through the host CLI)")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0: sized for ~10-30 s")
     ap.add_argument("--traffic-json", default=None,
                     help="per-launch HBM bytes from the rocprofv3 PMC passes (default: profiles/spmv_traffic[_<size>].json)")
@@ -101,11 +113,13 @@ def host_topology():
 def measured_stream(ctx, N):
     """Streaming ceiling of THIS box: the library's own axpy-class kernel (sum_vectors, 24 B per
     element: two reads, one write) and copy (16 B) over N-vectors, wall-clocked over 100 queued launches."""
+    import ctypes as C_
     a, b, c = ctx.alloc(N), ctx.alloc(N), ctx.alloc(N)
     ctx.init_vector(a, 1.0); ctx.init_vector(b, 2.0)
     out = {}
     for name, fn, nbytes in (("triad", lambda: ctx.sum_vectors(c, a, b, 0.5), 24 * N),
-                             ("copy", lambda: ctx.copy_vector(c, a), 16 * N)):
+                             ("copy", lambda: ctx.copy_vector(c, a), 16 * N),
+                             ("read", lambda: ctx.check(ctx.lib.bis_sumsq_dev(ctx.h, C_.c_void_p(a.ptr), C_.c_int64(N), C_.c_void_p(c.ptr))), 8 * N)):
         for _ in range(5):
             fn()
         ctx.sync()
@@ -341,6 +355,226 @@ def cpu_baseline(size, precond, iters, threads=None, seconds=15.0, first_touch=F
                 ms_per_step=1e3 * secs / iters), hist
 
 
+SWEEP_CASES = (
+    # (key, workload text, generator, reorder)
+    ("hpcg256", "HPCG 256^3 27-point: strict triangles of A, D = diag(A) (-cg -p sgs / gs sweeps)", lambda c: c.gen_hpcg(256), None),
+    ("anderson256", "Anderson 256^3 7-point, shift 9 (config 4's GS sweep; same pattern as configs 2-3)", lambda c: c.gen_anderson(256, shift=9.0), None),
+    ("fem80x80x81", "fem:80,80,81 (config-5 stand-in WITH a grid hint, 1.56 M rows)", lambda c: c.gen_fem(80, 80, 81), None),
+    ("unstr80_asis", "unstr:80,80,80 as generated (config 5 as named: no grid, no locality, 135 wide levels)", lambda c: c.gen_unstr(80, 80, 80), None),
+    ("unstr80_rcm", "unstr:80,80,80 RCM-ordered (config 5 as a real mesh is solved: ~7 thousand levels)", lambda c: c.gen_unstr(80, 80, 80), "rcm"),
+)
+
+
+def load_sweep_traffic(key, direction, algorithmic):
+    """PMC HBM bytes per sweep from profiles/trsv_traffic.json (tools/trsv_traffic.py: separate FETCH_SIZE / WRITE_SIZE
+    passes of the sweep kernel of this workload, sentinel fill included); accepted between 0.9x and 12x the algorithmic bytes
+    (polls re-read operands; an ordering without locality fetches a line per 8-byte operand: unstr as generated moves 8x)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "trsv_traffic.json")))
+        t = tj["sweeps"][key][direction]["hbm_bytes_per_sweep"]
+    except Exception:
+        return None
+    return t if t and 0.9 * algorithmic <= t <= 3.0 * algorithmic else None
+
+
+def sweep_legs(ctx, sweeps=10, warm=3, only=None):
+    """Forward and backward natural-order sweeps, x = (D + T)^-1 b, on the strict triangles of each workload: `sweeps` timed
+    bis_sptrsv / bis_bsptrsv calls after `warm` (the first builds the plan), HIP events around every call on the library's
+    stream (bis_profile_read_sweeps).  roofline: achieved = (12 nnz_T + 28 N) / average sweep time."""
+    import numpy as np
+    out = {}
+    for key, text, gen, reorder in SWEEP_CASES:
+        if only and key not in only:
+            continue
+        t_setup = time.perf_counter()
+        A = gen(ctx)
+        if reorder:
+            perm = ctx.bfs_order(A, rcm=True)
+            B = ctx.permute(A, perm)
+            A.free()
+            A = B
+        N = A.n_rows
+        Ls, Us, D, Dinv = ctx.split_strict(A)
+        A.free(); Dinv.free()
+        b = ctx.upload(np.random.default_rng(21).uniform(-1, 1, N))
+        x = ctx.alloc(N)
+        rec = {"workload": text, "rows": N}
+        for direction, T, solve in (("forward", Ls, ctx.sptrsv), ("backward", Us, ctx.bsptrsv)):
+            for _ in range(warm):
+                solve(T, x, D, b)
+            ctx.sync()
+            ctx.profile(True)
+            for _ in range(sweeps):
+                solve(T, x, D, b)
+            ctx.sync()
+            ctx.profile(False)
+            n, ms = ctx.profile_read_sweeps()
+            ctx.profile_read()  # (drop the SpMV events a per-level path may have recorded)
+            avg_s = ms * 1e-3 / max(n, 1)
+            alg = 12 * T.nnz + 28 * N
+            traffic = load_sweep_traffic(key, direction, alg)
+            ach = alg / avg_s / 1e9
+            rec[direction] = {"nnz_T": T.nnz, "avg_sweep_ms": avg_s * 1e3, "sweeps": n,
+                              "roofline": {"bound": "hbm", "kernel": T.sweep_kernel(direction == "backward"), "achieved": ach,
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                                           "algorithmic_bytes_per_sweep": alg,
+                                           "moved_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                                           "note": "latency-bound: dependency levels x one wave's row latency (DESIGN.md section 4), not bandwidth"},
+                              "sweep_gflops": (2.0 * T.nnz + 2.0 * N) / avg_s / 1e9}
+        rec["setup_s"] = time.perf_counter() - t_setup - sum(rec[d]["avg_sweep_ms"] * 1e-3 * (sweeps + warm) for d in ("forward", "backward"))
+        for v in (Ls, Us):
+            v.free()
+        for v in (D, b, x):
+            v.free()
+        out[key] = rec
+    return out
+
+
+CLI = os.path.join(ROOT, "basic_iterative_solvers_amd", "host", "basic_iterative_solvers")
+CONFIG_RUNS = (
+    ("config2", "Anderson 256^3 raw (indefinite: runs to MAX_ITERS), -cg", ["anderson:256", "-cg"]),
+    ("config3_1gpu", "Anderson 256^3 shift 9, -cg -p j on ONE GPU (config 3 is the 8-GPU partition of this)", ["anderson:256,shift=9", "-cg", "-p", "j"]),
+    ("config4", "Anderson 256^3 shift 9, -gm -p gs (GMRES(10) + natural-order GS sweep)", ["anderson:256,shift=9", "-gm", "-p", "gs"]),
+    ("config5_standin", "fem:80,80,81 (grid-hinted stand-in), -bi -p ilu0", ["fem:80,80,81", "-bi", "-p", "ilu0"]),
+    ("config5_unstr_asis", "unstr:80,80,80 as generated, -bi -p ilu0", ["unstr:80,80,80", "-bi", "-p", "ilu0"]),
+    ("config5_unstr_rcm", "unstr:80,80,80 -perm rcm, -bi -p ilu0", ["unstr:80,80,80", "-bi", "-p", "ilu0", "-perm", "rcm"]),
+)
+_TIMER_KEYS = (("total_s", "Total elapsed time:"), ("preprocessing_s", "| Preprocessing time:"), ("factor_s", "| | Factor time:"),
+               ("solve_s", "| Solve time:"), ("iterate_s", "| | Iterate time:"), ("spmv_s", "| | | SpMV time:"), ("precond_s", "| | | Precond. time:"),
+               ("dot_s", "Dot time:"), ("sum_s", "Sum time:"), ("orthog_s", "| | | Orthog. time:"), ("sample_s", "| | Sample time:"))
+
+
+def _run_cli(args, sync_timers, timeout=180):
+    """One run of the host CLI (the C++ host layer over the C ABI, a child process); returns the parsed summary or an error."""
+    import re
+    import subprocess
+    env = dict(os.environ)
+    env["BIS_TIMERS_SYNC"] = "1" if sync_timers else "0"
+    env.setdefault("OMP_NUM_THREADS", "1")
+    try:
+        r = subprocess.run([CLI] + list(args), capture_output=True, text=True, timeout=timeout, env=env)
+    except Exception as e:  # missing binary, timeout
+        return {"error": repr(e)[:200]}
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    m = re.search(r"(converged in: |did not converge after )(\d+) iterations", r.stdout)
+    out = {"iterations": int(m.group(2)) if m else None, "converged": bool(m and m.group(1).startswith("converged"))}
+    last = {}
+    for line in r.stdout.splitlines():
+        for k, label in _TIMER_KEYS:
+            if label in line:
+                try:
+                    last[k] = float(line.split(label)[1].strip().split("[")[0])
+                except Exception:
+                    pass
+        if line.startswith("Device library options in effect:"):
+            out["options"] = line.split(":", 1)[1].strip()
+    out.update(last)  # (the timer tree is printed at the milestones too: the LAST print is the whole run)
+    res = re.findall(r"\|\|A\*x_(\d+) - b\|\|_2 = (\S+)", r.stdout)
+    if res:
+        out["residual_first"], out["residual_last"] = float(res[0][1]), float(res[-1][1])
+    return out
+
+
+def config_legs(only=None):
+    """BASELINE configs 2, 4, 5 (and config 3's one-GPU form) through the library's own solver schedules (host CLI): a run
+    with asynchronous launches for the times that count (iterations, iterate time, preprocessing), and a second run with
+    the timer tree draining the stream per call (the reference's TIME semantics) for the SpMV / preconditioner / BLAS-1 split."""
+    out = {}
+    for key, text, args in CONFIG_RUNS:
+        if only and key not in only:
+            continue
+        a = _run_cli(args, sync_timers=False)
+        rec = {"workload": text, "command": " ".join(["basic_iterative_solvers"] + args)}
+        if "error" in a:
+            rec["error"] = a["error"]
+            out[key] = rec
+            continue
+        # solve_s = the reference's "Solve time" (iterate + sample + exchange, solver_harness.hpp:7-61): with asynchronous launches
+        # the device-scalar schedules only drain the stream where the residual is sampled, so the split below it is not
+        # meaningful in this run -- the second run gives it
+        rec.update({k: a.get(k) for k in ("iterations", "converged", "solve_s", "preprocessing_s", "factor_s", "total_s",
+                                          "residual_first", "residual_last", "options")})
+        if a.get("iterations") and a.get("solve_s"):
+            rec["ms_per_iteration"] = 1e3 * a["solve_s"] / a["iterations"]
+        b = _run_cli(args, sync_timers=True)
+        if "error" not in b and b.get("iterate_s"):
+            blas1 = sum(b.get(k) or 0.0 for k in ("dot_s", "sum_s", "orthog_s"))
+            rec["split_with_synchronous_timers"] = {
+                "iterate_s": b["iterate_s"], "spmv_s": b.get("spmv_s"), "precond_s": b.get("precond_s"), "blas1_s": blas1,
+                "spmv_share": (b.get("spmv_s") or 0.0) / b["iterate_s"], "precond_share": (b.get("precond_s") or 0.0) / b["iterate_s"],
+                "blas1_share": blas1 / b["iterate_s"]}
+        out[key] = rec
+    return out
+
+
+def cpu_sptrsv_leg(size=128, seconds=6.0):
+    """The reference's serial native_sptrsv / native_bsptrsv (kernels.hpp:54-107, from oracle/_ref; the oracle's restatement
+    where the prebuilt reference is absent) on HPCG-`size`: the CPU figure beside `sweeps` (one thread: the loop is serial)."""
+    import numpy as np
+
+    from oracle import pyoracle
+    orc = pyoracle.Oracle()
+    A = orc.gen_hpcg(size)
+    L, Ls, U, Us = orc.split_LU(A)
+    D, _, _ = orc.peel_diag(L)
+    del L, U
+    b = np.random.default_rng(21).uniform(-1, 1, A.n_rows)
+    kind = "reference" if pyoracle.Ref.available() else "port"
+    eng = pyoracle.Ref() if kind == "reference" else orc
+    rec = {"kind": kind, "cores": 1, "unit": "ms per sweep", "sample": f"HPCG {size}^3 strict triangles ({Ls.nnz} non-zeros each), "
+           "the reference's serial loop, best of the sweeps that fit a few seconds"}
+    for direction, T, backward in (("forward", Ls, False), ("backward", Us, True)):
+        best, t_end, n = None, time.time() + seconds / 2, 0
+        while n < 2 or (time.time() < t_end and n < 20):
+            t0 = time.perf_counter()
+            eng.sptrsv(T, D, b, backward=backward)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            n += 1
+        alg = 12 * T.nnz + 28 * A.n_rows
+        rec[direction] = {"ms_per_sweep": best * 1e3, "sweeps": n, "GBs_on_algorithmic_bytes": alg / best / 1e9}
+    rec["value"] = rec["forward"]["ms_per_sweep"]
+    return rec
+
+
+def cpu_topology(threads_list=(16, 64)):
+    """What explains the CPU leg: the cgroup's CPU quota, the NUMA nodes, where libgomp put the threads, and a host triad
+    (first touch by the same static schedule) at the thread counts the CG legs use."""
+    import ctypes as C
+
+    from oracle import pyoracle
+    topo = host_topology()
+    try:
+        topo["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except Exception:
+        topo["cgroup_cpu_max"] = None
+    try:
+        q, per = topo["cgroup_cpu_max"].split()
+        topo["cgroup_cpu_quota_cores"] = None if q == "max" else float(q) / float(per)
+    except Exception:
+        topo["cgroup_cpu_quota_cores"] = None
+    try:
+        topo["numa_nodes"] = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except Exception:
+        topo["numa_nodes"] = None
+    orc = pyoracle.Oracle()
+    orc.lib.orc_host_triad.restype = C.c_double
+    triad = {}
+    for t in threads_list:
+        if topo.get("logical_cpus") and t > topo["logical_cpus"]:
+            continue
+        pyoracle.set_omp_threads(t)
+        places = (C.c_int * 256)(*([-1] * 256))
+        gbs = orc.lib.orc_host_triad(C.c_int64(1 << 27), C.c_int(3), places, C.c_int(256))
+        cpus = [p for p in list(places)[:t] if p >= 0]
+        triad[str(t)] = {"GBs": gbs, "distinct_cpus": len(set(cpus)), "cpu_min": min(cpus) if cpus else None, "cpu_max": max(cpus) if cpus else None}
+    topo["host_triad"] = triad
+    topo["omp_proc_bind"] = os.environ.get("OMP_PROC_BIND")
+    topo["omp_places"] = os.environ.get("OMP_PLACES")
+    return topo
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>` as a child process, pass
@@ -437,7 +671,12 @@ def main():
     # the streaming ceiling measured on this box: the library's own triad over N-vectors
     roof["measured_stream_GBs"] = stream["triad"]
     roof["measured_copy_GBs"] = stream["copy"]
+    # the read-only stream (the sum of squares of an N-vector: 8 N bytes in, nothing out): the yardstick for a kernel that,
+    # like the SpMV, reads almost everything it moves -- the triad (two reads, one write) understates what reads can reach
+    roof["measured_read_GBs"] = stream["read"]
     roof["moved_frac_of_measured"] = roof["moved_GBs"] / stream["triad"]
+    roof["moved_frac_of_measured_read"] = roof["moved_GBs"] / stream["read"]
+    roof["algorithmic_frac"] = roof["frac"]  # (`frac` prices SURVEY 8d's algorithmic bytes; `moved_frac` the PMC traffic)
     vec_bytes = (80 if args.precond == "j" else 64) * N  # pass B 24 N (+16 N Jacobi), pass C 40 N
     out = {
         "metric": "CG iterations/sec + SpMV GFLOP/s (% HBM roofline), HPCG 256^3 at 1/2/4/8 GPUs",
@@ -476,7 +715,9 @@ def main():
                            "sliced ELL with the x window in LDS), bit-identical y; not a CRS-bandwidth figure")
             out["compressed_stream"] = leg
     if not args.no_cpu_baseline:
+        topo = cpu_topology()
         cb, cpu_hist = cpu_baseline(n1, args.precond, args.cpu_iters)
+        cb["topology"] = topo
         out["cpu_baseline"] = cb
         # parity against the CPU path on the same input over the CPU leg's WHOLE history: a fresh GPU run of as many
         # iterations as the reference made (the timed run above covers only warmup + steps of them)
@@ -496,7 +737,12 @@ def main():
         phys = (cb.get("topology") or {}).get("physical_cores") or 0
         socks = (cb.get("topology") or {}).get("sockets") or 1
         per_socket = phys // max(socks, 1)
-        if os.environ.get("BIS_CPU_SOCKET_LEG", "1") != "0":
+        quota = topo.get("cgroup_cpu_quota_cores")
+        if quota is not None and quota < per_socket:
+            # the container's CPU quota is below one socket: more threads than the quota are throttled, not faster -- the
+            # per-GPU share above IS the reference's best foot on this box
+            out["cpu_baseline_socket"] = {"skipped": f"cgroup cpu.max allows {quota:g} cores; a {per_socket}-thread leg would be throttled"}
+        elif os.environ.get("BIS_CPU_SOCKET_LEG", "1") != "0":
             if per_socket > cb["cores"]:
                 # a second sample on one full socket (fewer iterations), beside the per-GPU share of the host
                 cb2, _ = cpu_baseline(n1, args.precond, 0, threads=per_socket, seconds=5.0)
@@ -515,8 +761,17 @@ def main():
         if info["hbm_bytes"] >= 200e9:
             out["target_512"] = target_512(ctx)
             out["config5_spmv"] = unstructured_spmv(ctx)
+    if n1 == 256 and not args.no_sweeps:
+        out["sweeps"] = sweep_legs(ctx)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline_sptrsv"] = cpu_sptrsv_leg()
+    out["options"] = ctx.options()
+    out["options"]["placement_tuning"] = ("bis_mat_tune_placement: %d trials" % args.tune_placement) if args.tune_placement > 0 else \
+        "off (first allocation kept: boxes of the pool differ by 2-8 %, DESIGN.md section 6)"
+    ctx.close()  # (the child processes below get the whole device)
+    if n1 == 256 and not args.no_configs:
+        out["configs"] = config_legs()
     print(json.dumps(out), flush=True)
-    ctx.close()
 
 
 if __name__ == "__main__":

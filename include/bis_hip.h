@@ -91,6 +91,12 @@ BIS_API bis_status bis_device_info(bis_ctx *ctx, char *arch, size_t arch_len,
  * kernels only; 2 = host-built plan only, for tests).  Matrices created
  * afterwards pick them up. */
 BIS_API bis_status bis_set_option(const char *name, int value);
+/* The options in effect, for bench / CLI records (no reference counterpart:
+ * the reference fixes its configuration at compile time, CMakeLists.txt:19-29):
+ * a JSON object of every option that is not at its default, plus "env": the
+ * BIS_* environment variables this process found at first use.  Returns the
+ * length needed; writes at most cap - 1 characters and a terminator. */
+BIS_API int bis_options_describe(char *buf, int cap);
 /* number of exported kernel-level symbols, for the load test */
 BIS_API int bis_abi_version(void);
 
@@ -506,6 +512,14 @@ BIS_API bis_status bis_cg_status(bis_ctx *ctx, bis_cg *cg, int *iters,
  * bracketed by a hipEvent pair; bis_profile_read returns launches and the
  * summed duration in milliseconds and resets the counters (blocking). */
 BIS_API bis_status bis_profile_enable(bis_ctx *ctx, int on);
+/* ... and every bis_sptrsv / bis_bsptrsv call (all launches of the call, on the
+ * context's stream): count and summed milliseconds since the last read.
+ * bis_mat_sweep_kernel names the kernel the last sweep of that direction ran on
+ * the triangle (static string; "" before the first sweep) -- the timer-tree
+ * counterpart of the reference's LIKWID regions `sptrsv` / `backwards-sptrsv`
+ * (kernels.hpp:56-58, :90-92). */
+BIS_API bis_status bis_profile_read_sweeps(bis_ctx *ctx, int64_t *sweeps, double *sweep_ms);
+BIS_API const char *bis_mat_sweep_kernel(const bis_mat *T, int backward);
 BIS_API bis_status bis_profile_read(bis_ctx *ctx, int64_t *spmv_launches,
                                     double *spmv_ms);
 

@@ -1298,3 +1298,35 @@ ORC_API int orc_cg_run(int64_t n, const int64_t *row_ptr, const int32_t *col,
     free(z); free(zn);
     return 0;
 }
+
+/* ---- host-memory probe for bench.py's cpu_baseline.topology (no reference counterpart: it explains the CPU leg) ----
+ * STREAM-triad-shaped loop a[i] = b[i] + s c[i] -- the shape of the reference's sum_vectors (kernels.hpp:128-135) -- over
+ * vectors of n doubles that the SAME static OpenMP schedule touched first (the placement MatrixCRS::operator= gives the
+ * reference's arrays, sparse_matrix.hpp:92-128).  Returns GB/s (24 n bytes per pass), the best of `reps` passes.
+ * places_out (may be NULL): the CPU each of the first `cap` threads ran on, by sched_getcpu(). */
+extern int sched_getcpu(void); /* glibc; declared here so that the file needs no _GNU_SOURCE */
+ORC_API double orc_host_triad(int64_t n, int reps, int *places_out, int cap) {
+    double *a = dalloc(n), *b = dalloc(n), *c = dalloc(n);
+    if (!a || !b || !c) { free(a); free(b); free(c); return -1.0; }
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+        if (places_out && t < cap) places_out[t] = sched_getcpu();
+#endif
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
+    }
+    double best = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        const double t0 = wall_now();
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) a[i] = b[i] + 0.5 * c[i];
+        const double dt = wall_now() - t0;
+        const double gbs = 24.0 * (double)n / dt / 1e9;
+        if (gbs > best) best = gbs;
+    }
+    volatile double sink = a[n / 2]; (void)sink;
+    free(a); free(b); free(c);
+    return best;
+}
