@@ -59,9 +59,16 @@ def cg_leg(E, args, n1, matrix, precond, shift, steps, warmup, valdict):
     -1: the library's default stream format for the matrix."""
     import torch
     td, ctx, rank, world = E.td, E.ctx, E.rank, E.world
-    from . import BisError, Dist
-    from .launcher import even_row_starts, route_send_lists, setup_rccl, torch_comm_ops
+    from . import BisError, Dist, rccl_unique_id
+    from .launcher import even_row_starts, negotiate_rccl_id, route_send_lists, torch_comm_ops
 
+    def stage(name):  # a phase of the watchdog's board; inside the north-star leg every stage is a checkpoint of `512-leg`
+        if E.leg_phase:
+            E.wd.tick(name)
+        else:
+            E.wd.enter(name)
+
+    stage("gen")
     N = n1 ** 3
     ctx.set_option("spmv_valdict", valdict)
     row_starts = even_row_starts(N, world, align=n1 * n1)
@@ -76,14 +83,21 @@ def cg_leg(E, args, n1, matrix, precond, shift, steps, warmup, valdict):
     if precond == "j":  # the Jacobi diagonal of this rank's rows, taken before the columns are renumbered
         D, Dinv = ctx.mat_diag(A, row0)
         Dinv.free()
+    E.wd.tick("slab generated")
     d = Dist(ctx, A, rank, world, row_starts)
     setup_s = time.perf_counter() - t_setup
+    E.wd.tick("halo plan made")
     route_send_lists(d, td, group=E.host_group)
     transport = "rccl (native ncclSend/ncclRecv + ncclAllReduce on the library's streams)"
     try:
         if E.rehearse:
             raise BisError("rehearsal: RCCL cannot put two ranks on one GPU")
-        setup_rccl(ctx, d, td, group=E.host_group)
+        stage("rccl-id")
+        uid, why = negotiate_rccl_id(td, rank, world, lambda: rccl_unique_id(ctx), E.host_group)
+        if uid is None:
+            raise BisError(f"native RCCL transport unavailable: {why}")
+        stage("comm-init")
+        d.use_rccl(uid)  # ncclCommInitRank: collective
         ok = 1
     except (BisError, OSError, RuntimeError) as ex:  # e.g. RCCL not loadable: fall back to torch.distributed's communicator
         print(f"rank {rank}: native RCCL transport unavailable ({ex}); using torch.distributed", flush=True)
@@ -93,6 +107,7 @@ def cg_leg(E, args, n1, matrix, precond, shift, steps, warmup, valdict):
     if int(flag.item()) == 0:
         d.set_comm(torch_comm_ops(td, torch, world, rank))
         transport = "torch.distributed through the C-ABI communicator callbacks"
+    E.wd.tick("transport chosen")
     nl = d.n_local
     b, x = ctx.alloc(nl), ctx.alloc(nl)
     ctx.init_vector(b, 1.0)
@@ -104,12 +119,15 @@ def cg_leg(E, args, n1, matrix, precond, shift, steps, warmup, valdict):
     r0_exact = r0_closed_form(matrix, shift, n1)
     if not abs(r0 - r0_exact) <= 1e-10 * r0_exact:
         raise SystemExit(f"rank {rank}: distributed residual {r0!r} != {r0_exact!r}: partitioned operator is wrong")
+    stage("warmup")
     cg.iterate(warmup)
     ctx.sync()
     torch.cuda.synchronize()
+    E.wd.tick("warm-up iterations done")
     td.barrier()
     torch.cuda.synchronize()
 
+    stage("timed")
     ctx.profile(True)
     t0 = time.perf_counter()
     cg.iterate(steps)
@@ -117,6 +135,7 @@ def cg_leg(E, args, n1, matrix, precond, shift, steps, warmup, valdict):
     td.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    stage("report")
     ctx.profile(False)
     launches, spmv_ms = ctx.profile_read()
     comm = d.profile_read()
@@ -149,6 +168,10 @@ def cg_leg(E, args, n1, matrix, precond, shift, steps, warmup, valdict):
     td.all_reduce(mx, op=td.ReduceOp.MAX)
     nnz = int(tot[0].item())
     rec = None
+    seen = [p["rccl_ranks_seen"] for p in per_rank]
+    if transport.startswith("rccl") and any(v != world for v in seen):
+        # the communicator every rank built must span the whole world: anything else is a partition that exchanged with nobody
+        raise SystemExit(f"rank {rank}: RCCL communicators span {seen} ranks, expected {world} on every rank")
     if rank == 0:
         if iters != warmup + steps:
             raise SystemExit(f"timed region invalid: {iters} iterations executed")
@@ -174,7 +197,7 @@ def cg_leg(E, args, n1, matrix, precond, shift, steps, warmup, valdict):
                                     "2 all-reduces per iteration"},
             "spmv_gflops": 2.0 * nnz / spmv_avg_s / 1e9,
             "residual_r0": r0, "residual_r0_closed_form": r0_exact, "residual_last": float(hist[-1]),
-            "transport": transport, "per_rank": per_rank,
+            "transport": transport, "rccl_ranks_seen": min(seen), "per_rank": per_rank,
             "roofline": {"bound": "hbm", "kernel": kernel + " (interior + boundary launches; rank 0's interior rows)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
@@ -210,7 +233,11 @@ def run_distributed(args, rank, world, local_rank):
     os.dup2(2, 1)
     # BIS_BENCH_REHEARSE=1 (tests on a one-GPU box): every rank uses cuda:0, gloo process group,
     # torch.distributed transport through the C-ABI callbacks -- everything of this function except RCCL.
+    from .watchdog import RankWatchdog
     E = _Env()
+    # from here on a rank that outlives a phase limit ends the run with ONE diagnostic JSON line on the bench's stdout
+    E.wd = RankWatchdog(rank, world, out_fd=saved_stdout)
+    E.leg_phase = None
     E.rehearse = os.environ.get("BIS_BENCH_REHEARSE") == "1"
     if E.rehearse:
         local_rank = 0
@@ -242,21 +269,29 @@ def run_distributed(args, rank, world, local_rank):
         info = ctx.device_info()
         slab_bytes = 12.0 * 27 * (t512 ** 3) / world * 1.35 + 8.0 * 12 * (t512 ** 3) / world
         if info["hbm_bytes"] * (0.5 if E.rehearse else 0.85) >= slab_bytes * (world if E.rehearse else 1):
+            E.wd.enter("512-leg")
+            E.leg_phase = "512-leg"
             t = cg_leg(E, args, t512, "hpcg", "none", 0.0, args.target_steps, 3, 0)
+            E.wd.enter("512-leg")  # (a fresh fuse for the second format's leg)
             tc = cg_leg(E, args, t512, "hpcg", "none", 0.0, args.target_steps, 3, -1)
+            E.leg_phase = None
             if rank == 0:
                 if tc["per_rank"][0]["spmv_stream"]["val_bytes"] < 8:
                     t["compressed_stream"] = tc
                 extra["target_%d" % t512] = t
+    E.wd.enter("report")
     if rank == 0:
         rec = {"metric": "CG iterations/sec + SpMV GFLOP/s (% HBM roofline), HPCG 256^3 at 1/2/4/8 GPUs",
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
         rec.update(out)
         rec.update(extra)
+        rec["options"] = ctx.options()
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(rec), flush=True)
         os.dup2(2, 1)
     td.barrier()
+    E.wd.enter("done")
+    E.wd.stop()
     ctx.close()
     td.destroy_process_group()

@@ -577,10 +577,11 @@ def cpu_topology(threads_list=(16, 64)):
 
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nnodes=1
-    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>` as a child process, pass
-    its stdout (rank 0's ONE JSON line) through and return its exit code."""
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>` as a child process group,
+    pass its stdout (rank 0's ONE JSON line) through and return its exit code."""
     import socket
-    import subprocess
+
+    from basic_iterative_solvers_amd.watchdog import supervise
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -589,7 +590,9 @@ def launch_ranks(n):
     env.setdefault("OMP_NUM_THREADS", "1")  # (torchrun would set it, with a warning on stderr)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # the ranks run as a child process group under a watchdog (basic_iterative_solvers_amd/watchdog.py): a rank that outlives
+    # a phase limit ends the run with ONE diagnostic JSON line {"error", "phase", "rank", ...} and a non-zero status
+    return supervise(cmd, n, env=env)
 
 
 def main():

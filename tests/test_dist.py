@@ -126,3 +126,63 @@ def test_bench_refuses_a_world_that_does_not_match_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode != 0 and "--gpus 4" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["own-launcher", "torch.distributed.run"])
+def test_bench_stuck_rank_is_reported(how):
+    """A rank that gets stuck must not leave a run that is killed at the driver's limit with nothing written (round-4 verdict,
+    item 4): with a rank put to sleep at the start of its `gen` phase (BIS_BENCH_STUCK) and the phase limit at 20 s, bench.py
+    --gpus 2 -- started plainly (its own launcher + the parent watchdog) and exactly as the driver starts it -- ends with a
+    non-zero status and ONE JSON line that names the rank and the phase, within the limit plus start-up."""
+    import json
+    import time
+    args = ["--gpus", "2", "--size", "32", "--steps", "4", "--warmup", "1", "--target-size", "0"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", BIS_BENCH_REHEARSE="1", BIS_BENCH_STUCK="1:gen:900", BIS_PHASE_LIMIT_S="20")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BIS_PHASE_DIR"):
+        env.pop(k, None)
+    if how == "own-launcher":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + args
+    t0 = time.time()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    secs = time.time() - t0
+    assert out.returncode != 0, out.stdout[-2000:]
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = lines[0]
+    assert d["rank"] == 1 and d["phase"] == "gen" and "error" in d and d["n_gpus"] == 2, d
+    assert d["phases"]["0"].startswith("gen") and "halo plan made" in d["phases"]["0"]  # rank 0 waits in the routing collective
+    assert "[bis-phase] rank=1 phase=gen" in out.stderr
+    assert secs < 20 + 150, secs  # the limit + interpreter / torch start-up on a fresh box, not the 900 s of the sleeper
+
+
+@pytest.mark.gpu
+def test_bench_distributed_code_path_at_one_rank_agrees_with_the_plain_one():
+    """`--gpus 1` under BIS_FORCE_DIST=1 runs the partitioned code path (a 1-rank communicator, RCCL where it loads: halo plan,
+    interior / boundary launches, device all-reduces) on the metric's problem; its rate must agree with the plain path's
+    within 3 % -- what the N > 1 records inherit from N = 1 is then the same kernel at the same speed."""
+    import json
+
+    def run(extra_env):
+        env = dict(os.environ, OMP_NUM_THREADS="1", **extra_env)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BIS_PHASE_DIR", "BIS_BENCH_REHEARSE"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "10",
+                              "--no-cpu-baseline", "--no-target-512", "--no-sweeps", "--no-configs"],
+                             capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    plain = run({})
+    dist = run({"BIS_FORCE_DIST": "1"})
+    assert dist["n_gpus"] == 1 and "transport" in dist and dist["config"]["rows"] == 256 ** 3
+    if dist["transport"].startswith("rccl"):
+        assert dist["rccl_ranks_seen"] == 1
+    assert plain["roofline"]["spmv_stream"]["val_bytes"] == 8 and dist["per_rank"][0]["spmv_stream"]["val_bytes"] == 8
+    ratio = dist["value"] / plain["value"]
+    assert 0.97 <= ratio <= 1.03, (plain["value"], dist["value"])
