@@ -1,22 +1,51 @@
 // bis_blas1.hip -- context, vectors and the BLAS-1 class kernels of the hot
 // path (reference kernels.hpp:119-257, methods/jacobi.hpp:27-40) as
 // hand-written gfx950 HIP kernels.  All of them are HBM-bound streaming
-// kernels: 16 B per lane (double2) loads/stores, grid capped at 2048
-// workgroups with a grid-stride loop (cdna_hip_programming.md Guideline 11/13).
+// kernels: 16 B per lane (double2) accesses in a grid-stride loop.
+//
+// What the streams want on MI355X (tools/blas1_bench.hip, N = 16.8 M, operands ROTATING through 8 vectors so that nothing is
+// served by the 256 MB Infinity Cache; profiles/r05_b_blas1_variants.log): r = a + s b moves 5.3-5.7 TB/s with plain loads
+// and stores, 6.4-6.7 with NON-TEMPORAL LOADS and plain stores, 5.9-6.25 with both non-temporal, 5.5-5.7 with non-temporal
+// stores only; two or four independent 16-byte accesses per operand in flight per lane LOSE 3-10 % against one (the waves
+// of 8 workgroups per CU already cover the latency; more registers per lane buy nothing), a block-contiguous split instead
+// of the grid stride is a wash; grids of 8-16 thousand workgroups gain 2-4 % over 2048.  So: every input stream of the
+// elementwise kernels and of the reductions is read with non-temporal loads (a streamed operand does not displace the
+// lines the neighbouring kernels of a solver iteration re-use: x-vector tiles of the SpMV, sweep operands), stores stay
+// plain (the next kernel of the iteration usually reads what this one wrote), one access per operand per lane and
+// iteration, elementwise grids up to 16384 workgroups, reductions up to 8192 (kMaxDotBlocks: their partial sums -- and with
+// them the bits of a dot product -- are a function of the grid, so every kernel that reproduces a dot shares that constant).
 #include "bis_internal.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
 
 constexpr int kEwThreads = 256;
+constexpr int kMaxEwBlocks = 16384; // elementwise kernels (no partial sums: the grid is free)
 
+// grid of a reduction (its partials are indexed by block: at most kMaxDotBlocks of them)
 inline int ew_grid(int64_t n_items) {
     int64_t g = (n_items + kEwThreads - 1) / kEwThreads;
     if (g < 1) g = 1;
-    if (g > kMaxReduceBlocks) g = kMaxReduceBlocks;
+    if (g > kMaxDotBlocks) g = kMaxDotBlocks;
     return (int)g;
 }
+// grid of an elementwise kernel
+inline int ew_grid_wide(int64_t n_items) {
+    int64_t g = (n_items + kEwThreads - 1) / kEwThreads;
+    if (g < 1) g = 1;
+    if (g > kMaxEwBlocks) g = kMaxEwBlocks;
+    return (int)g;
+}
+
+// streamed (single-touch) input: non-temporal load
+typedef double ew_v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_stream(const double2 *p) {
+    const ew_v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const ew_v2d_t *>(p));
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -44,7 +73,7 @@ __global__ __launch_bounds__(kEwThreads) void ew3_kernel(double *r, const double
         const double2 *b2 = reinterpret_cast<const double2 *>(b);
         double2 *r2 = reinterpret_cast<double2 *>(r);
         for (; i < n2; i += stride) {
-            double2 av = a2[i], bv = b2[i], rv;
+            double2 av = ld_stream(a2 + i), bv = ld_stream(b2 + i), rv;
             rv.x = ew_apply<OP>(av.x, bv.x, s);
             rv.y = ew_apply<OP>(av.y, bv.y, s);
             r2[i] = rv;
@@ -52,7 +81,7 @@ __global__ __launch_bounds__(kEwThreads) void ew3_kernel(double *r, const double
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
             r[n - 1] = ew_apply<OP>(a[n - 1], b[n - 1], s);
     } else {
-        for (; i < n; i += stride) r[i] = ew_apply<OP>(a[i], b[i], s);
+        for (; i < n; i += stride) r[i] = ew_apply<OP>(ld_stream(a + i), ld_stream(b + i), s);
     }
 }
 
@@ -73,7 +102,7 @@ __global__ __launch_bounds__(kEwThreads) void ew2_kernel(double *r, const double
             if (OP == U_FILL) {
                 rv.x = s; rv.y = s;
             } else {
-                double2 av = a2[i];
+                double2 av = ld_stream(a2 + i);
                 rv.x = (OP == U_SCALE) ? av.x * s : av.x;
                 rv.y = (OP == U_SCALE) ? av.y * s : av.y;
             }
@@ -95,9 +124,9 @@ __global__ __launch_bounds__(kEwThreads) void normalize_x_kernel(double *x_new,
                                                                  int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * kEwThreads;
     for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += stride) {
-        const double d = D[i];
-        const double adjusted = fma(-d, x_old[i], x_new[i]);
-        x_new[i] = (b[i] - adjusted) / d;
+        const double d = ld_stream(D + i);
+        const double adjusted = fma(-d, ld_stream(x_old + i), ld_stream(x_new + i));
+        x_new[i] = (ld_stream(b + i) - adjusted) / d;
     }
 }
 
@@ -110,13 +139,14 @@ __global__ __launch_bounds__(kEwThreads) void multi_axpy_kernel(const double *V,
     const int64_t stride = (int64_t)gridDim.x * kEwThreads;
     for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < n; i += stride) {
         double acc = 0.0;
-        for (int k = 0; k < n_vec; ++k) acc = fma(V[(int64_t)k * ldv + i], c.y[k], acc);
+        for (int k = 0; k < n_vec; ++k) acc = fma(ld_stream(V + (int64_t)k * ldv + i), c.y[k], acc);
         out[i] = acc;
     }
 }
 
-// partials[blockIdx.x] = sum over this block's grid-stride share of a[i]*b[i].
-template <bool VEC>
+// partials[blockIdx.x] = sum over this block's grid-stride share of a[i]*b[i].  SAME: b is a (a sum of squares: one load per
+// element instead of two of the same line; the same products, the same sums).
+template <bool VEC, bool SAME>
 __global__ __launch_bounds__(kEwThreads) void dot_partial_kernel(const double *a,
                                                                  const double *b, int64_t n,
                                                                  double *partials) {
@@ -129,14 +159,14 @@ __global__ __launch_bounds__(kEwThreads) void dot_partial_kernel(const double *a
         const double2 *a2 = reinterpret_cast<const double2 *>(a);
         const double2 *b2 = reinterpret_cast<const double2 *>(b);
         for (; i < n2; i += stride) {
-            double2 av = a2[i], bv = b2[i];
+            const double2 av = ld_stream(a2 + i), bv = SAME ? av : ld_stream(b2 + i);
             acc0 = fma(av.x, bv.x, acc0);
             acc1 = fma(av.y, bv.y, acc1);
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
             acc0 = fma(a[n - 1], b[n - 1], acc0);
     } else {
-        for (; i < n; i += stride) acc0 = fma(a[i], b[i], acc0);
+        for (; i < n; i += stride) { const double av = ld_stream(a + i); acc0 = fma(av, SAME ? av : ld_stream(b + i), acc0); }
     }
     const double s = block_sum<kEwThreads>(acc0 + acc1, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -159,12 +189,12 @@ __global__ __launch_bounds__(kEwThreads) void axpy_dot_kernel(double *w, const d
         const double2 *u2 = reinterpret_cast<const double2 *>(u);
         const double2 *v2 = reinterpret_cast<const double2 *>(v);
         for (; i < n2; i += stride) {
-            double2 wv = w2[i];
-            const double2 uv = u2[i];
+            double2 wv = ld_stream(w2 + i);
+            const double2 uv = ld_stream(u2 + i);
             wv.x = ew_apply<OP_SUB>(wv.x, uv.x, s);
             wv.y = ew_apply<OP_SUB>(wv.y, uv.y, s);
             w2[i] = wv;
-            const double2 vv = v ? v2[i] : wv;
+            const double2 vv = v ? ld_stream(v2 + i) : wv;
             acc0 = fma(wv.x, vv.x, acc0);
             acc1 = fma(wv.y, vv.y, acc1);
         }
@@ -328,7 +358,7 @@ bis_status bis_ctx_create(int device, void *stream, bis_ctx **out) {
         }
         ctx->own_stream = true;
     }
-    ctx->partials_cap = (size_t)kMaxReduceBlocks * 4;
+    ctx->partials_cap = std::max((size_t)kMaxReduceBlocks * 4, (size_t)kMaxDotBlocks * 2);
     bool ok = hipMalloc(&ctx->partials, sizeof(double) * ctx->partials_cap) == hipSuccess &&
               hipMalloc(&ctx->scalars_dev, sizeof(double) * 64) == hipSuccess &&
               hipHostMalloc(&ctx->scalars_host, sizeof(double) * 64) == hipSuccess &&
@@ -432,10 +462,10 @@ static bis_status launch_ew3(bis_ctx *ctx, double *r, const double *a, const dou
     if (n == 0) return BIS_OK;
     const bool vec = aligned16(r) && aligned16(a) && aligned16(b) && n >= 2;
     if (vec)
-        hipLaunchKernelGGL((ew3_kernel<OP, true>), dim3(ew_grid(n >> 1)), dim3(kEwThreads), 0,
+        hipLaunchKernelGGL((ew3_kernel<OP, true>), dim3(ew_grid_wide(n >> 1)), dim3(kEwThreads), 0,
                            ctx->stream, r, a, b, n, s, s_dev);
     else
-        hipLaunchKernelGGL((ew3_kernel<OP, false>), dim3(ew_grid(n)), dim3(kEwThreads), 0,
+        hipLaunchKernelGGL((ew3_kernel<OP, false>), dim3(ew_grid_wide(n)), dim3(kEwThreads), 0,
                            ctx->stream, r, a, b, n, s, s_dev);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
@@ -484,10 +514,10 @@ static bis_status launch_ew2(bis_ctx *ctx, double *r, const double *a, int64_t n
     if (n == 0) return BIS_OK;
     const bool vec = aligned16(r) && (OP == U_FILL || aligned16(a)) && n >= 2;
     if (vec)
-        hipLaunchKernelGGL((ew2_kernel<OP, true>), dim3(ew_grid(n >> 1)), dim3(kEwThreads), 0,
+        hipLaunchKernelGGL((ew2_kernel<OP, true>), dim3(ew_grid_wide(n >> 1)), dim3(kEwThreads), 0,
                            ctx->stream, r, a, n, s, s_dev);
     else
-        hipLaunchKernelGGL((ew2_kernel<OP, false>), dim3(ew_grid(n)), dim3(kEwThreads), 0,
+        hipLaunchKernelGGL((ew2_kernel<OP, false>), dim3(ew_grid_wide(n)), dim3(kEwThreads), 0,
                            ctx->stream, r, a, n, s, s_dev);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
@@ -515,7 +545,7 @@ bis_status bis_normalize_x(bis_ctx *ctx, double *x_new, const double *x_old, con
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, n >= 0 && (n == 0 || (x_new && x_old && D && b)), "bis_normalize_x: bad arguments");
     if (n == 0) return BIS_OK;
-    hipLaunchKernelGGL(normalize_x_kernel, dim3(ew_grid(n)), dim3(kEwThreads), 0, ctx->stream,
+    hipLaunchKernelGGL(normalize_x_kernel, dim3(ew_grid_wide(n)), dim3(kEwThreads), 0, ctx->stream,
                        x_new, x_old, D, b, n);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
@@ -530,7 +560,7 @@ bis_status bis_multi_axpy(bis_ctx *ctx, const double *V, int64_t ldv, const doub
     if (n == 0) return BIS_OK;
     MultiAxpyCoef c;
     for (int k = 0; k < 64; ++k) c.y[k] = k < n_vec ? y_host[k] : 0.0;
-    hipLaunchKernelGGL(multi_axpy_kernel, dim3(ew_grid(n)), dim3(kEwThreads), 0, ctx->stream, V,
+    hipLaunchKernelGGL(multi_axpy_kernel, dim3(ew_grid_wide(n)), dim3(kEwThreads), 0, ctx->stream, V,
                        ldv, c, n_vec, out, n);
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return BIS_OK;
@@ -543,12 +573,10 @@ bis_status bis_dot_dev(bis_ctx *ctx, const double *a, const double *b, int64_t n
     BIS_REQUIRE(ctx, n >= 0 && result_dev && (n == 0 || (a && b)), "bis_dot: bad arguments");
     const bool vec = aligned16(a) && aligned16(b) && n >= 2;
     const int grid = n == 0 ? 1 : (vec ? ew_grid(n >> 1) : ew_grid(n));
-    if (vec)
-        hipLaunchKernelGGL((dot_partial_kernel<true>), dim3(grid), dim3(kEwThreads), 0,
-                           ctx->stream, a, b, n, ctx->partials);
-    else
-        hipLaunchKernelGGL((dot_partial_kernel<false>), dim3(grid), dim3(kEwThreads), 0,
-                           ctx->stream, a, b, n, ctx->partials);
+#define BIS_DOT_LAUNCH(V, S) hipLaunchKernelGGL((dot_partial_kernel<V, S>), dim3(grid), dim3(kEwThreads), 0, ctx->stream, a, b, n, ctx->partials)
+    if (vec) { if (a == b) BIS_DOT_LAUNCH(true, true); else BIS_DOT_LAUNCH(true, false); }
+    else { if (a == b) BIS_DOT_LAUNCH(false, true); else BIS_DOT_LAUNCH(false, false); }
+#undef BIS_DOT_LAUNCH
     BIS_HIP_CHECK(ctx, hipGetLastError());
     return bis_reduce_finish(ctx, grid, 1, 0, result_dev);
 }

@@ -111,6 +111,10 @@ struct bis_options {
 inline bool bis_want_rp64(int64_t nnz) { return nnz >= (int64_t)INT32_MAX - 8 || bis_opts().force_rp64 > 0; }
 
 constexpr int kMaxReduceBlocks = 2048;
+// workgroups (= partial sums) of the stand-alone reductions -- dot, sum of squares, the fused axpy + dot, the Jacobi step's
+// residual norm: 16 N bytes of two non-temporal read streams move 5.9 TB/s from a grid of 2048, 6.3 from 4096, 6.4 from 8192
+// (tools/blas1_bench.hip).  One constant for all of them: kernels that promise the bits of "ew3 then dot" share the index map.
+constexpr int kMaxDotBlocks = 8192;
 constexpr int kWinMaxTiles = 128; // x window: at most 128 tiles of 16 columns (16 KiB of LDS)
 constexpr int kWinTile = 16;
 constexpr int kWinTileLog = 4;

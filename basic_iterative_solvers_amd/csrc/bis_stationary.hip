@@ -47,7 +47,7 @@ constexpr int kT = 256;
 inline int ew_grid(int64_t n_items) {
     int64_t g = (n_items + kT - 1) / kT;
     if (g < 1) g = 1;
-    if (g > kMaxReduceBlocks) g = kMaxReduceBlocks;
+    if (g > kMaxDotBlocks) g = kMaxDotBlocks; // (the index map of dot_partial_kernel: bis_blas1.hip)
     return (int)g;
 }
 
@@ -164,7 +164,7 @@ bis_status bis_stat_init(bis_ctx *ctx, bis_stat *s, double tol, double *r0_norm_
     BIS_CTX_OK(ctx);
     BIS_REQUIRE(ctx, s, "bis_stat_init: null handle");
     const int64_t n = s->n;
-    bis_status st = bis_ensure_partials(ctx, (size_t)2 * kMaxReduceBlocks);
+    bis_status st = bis_ensure_partials(ctx, (size_t)2 * kMaxDotBlocks);
     if (st != BIS_OK) return st;
     double *r = s->kind == BIS_STAT_JACOBI ? s->xb : s->r; // (Jacobi: buffer 1 is free until the first step)
     st = bis_compute_residual(ctx, s->A, s->x, s->b, r, s->t); // leaves t = A x_0: the first Jacobi step starts from it

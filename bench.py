@@ -111,16 +111,29 @@ def host_topology():
 
 
 def measured_stream(ctx, N):
-    """Streaming ceiling of THIS box: the library's own axpy-class kernel (sum_vectors, 24 B per
-    element: two reads, one write) and copy (16 B) over N-vectors, wall-clocked over 100 queued launches."""
+    """Streaming ceilings of THIS box with the library's own kernels over N-vectors, wall-clocked over 100 queued launches:
+    triad (sum_vectors, 24 B per element: two reads, one write), copy (16 B) and read (the sum of squares, 8 B in, nothing
+    out).  The operands ROTATE through eight vectors (1 GB at N = 16.8 M), so that no launch finds its inputs in the 256 MB
+    Infinity Cache: with three fixed vectors the same kernels measure 5-15 % more, which is cache, not HBM."""
     import ctypes as C_
-    a, b, c = ctx.alloc(N), ctx.alloc(N), ctx.alloc(N)
-    ctx.init_vector(a, 1.0); ctx.init_vector(b, 2.0)
+    v = [ctx.alloc(N) for _ in range(8)]
+    for i, w in enumerate(v):
+        ctx.init_vector(w, 1.0 + i)
+    scratch = ctx.alloc(8)
+    k = [0]
+
+    def triad():
+        ctx.sum_vectors(v[k[0] % 8], v[(k[0] + 3) % 8], v[(k[0] + 6) % 8], 0.5); k[0] += 1
+
+    def copy():
+        ctx.copy_vector(v[k[0] % 8], v[(k[0] + 3) % 8]); k[0] += 1
+
+    def read():
+        ctx.check(ctx.lib.bis_sumsq_dev(ctx.h, C_.c_void_p(v[k[0] % 8].ptr), C_.c_int64(N), C_.c_void_p(scratch.ptr))); k[0] += 1
+
     out = {}
-    for name, fn, nbytes in (("triad", lambda: ctx.sum_vectors(c, a, b, 0.5), 24 * N),
-                             ("copy", lambda: ctx.copy_vector(c, a), 16 * N),
-                             ("read", lambda: ctx.check(ctx.lib.bis_sumsq_dev(ctx.h, C_.c_void_p(a.ptr), C_.c_int64(N), C_.c_void_p(c.ptr))), 8 * N)):
-        for _ in range(5):
+    for name, fn, nbytes in (("triad", triad, 24 * N), ("copy", copy, 16 * N), ("read", read, 8 * N)):
+        for _ in range(8):
             fn()
         ctx.sync()
         t0 = time.perf_counter()
@@ -128,8 +141,11 @@ def measured_stream(ctx, N):
             fn()
         ctx.sync()
         out[name] = 100 * nbytes / (time.perf_counter() - t0) / 1e9
-    for v in (a, b, c):
-        v.free()
+    # (`read` is two launches per pass -- the partial sums and their 1-workgroup finish: at 21 us per pass the boundary
+    # between them is ~10 % of the wall time, so this figure understates the kernel's own rate, 6.3-6.4 TB/s under rocprofv3)
+    for w in v:
+        w.free()
+    scratch.free()
     return out
 
 

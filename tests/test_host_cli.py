@@ -22,6 +22,7 @@ MATRIX_ARG = {
     "hpcg8": "hpcg:8",
     "hpcg_4x6x5": "hpcg:4,6,5",
     "anderson8_shift9": "anderson:8,shift=9",
+    "hpcg176": "hpcg:176",
 }
 
 _H = load_histories()
@@ -145,6 +146,17 @@ def test_cli_stationary_device_schedule_equals_unfused(name, solver):
     where the solver does not converge: FDM-2d-16 -j runs to MAX_ITERS in the reference)."""
     a = run_cli(name, solver, "none", {})
     b = run_cli(name, solver, "none", {}, extra=["-unfused"])
+    assert a["iters"] == b["iters"] and a["converged"] == b["converged"]
+    assert len(a["hist"]) == len(b["hist"]) and np.array_equal(a["hist"], b["hist"])
+
+
+@pytest.mark.parametrize("solver", ["j", "gs"])
+def test_cli_stationary_device_schedule_equals_unfused_above_the_grid_caps(solver):
+    """The same identity at 5.45 M rows (HPCG 176^3): above 8192 x 512 elements the reductions' grids sit at their cap
+    (kMaxDotBlocks), and the Jacobi step's fused residual norm must share the index map of the stand-alone dot to stay
+    digit-identical with the kernel-by-kernel schedule."""
+    a = run_cli("hpcg176", solver, "none", {})
+    b = run_cli("hpcg176", solver, "none", {}, extra=["-unfused"])
     assert a["iters"] == b["iters"] and a["converged"] == b["converged"]
     assert len(a["hist"]) == len(b["hist"]) and np.array_equal(a["hist"], b["hist"])
 
