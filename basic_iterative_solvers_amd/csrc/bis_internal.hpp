@@ -101,6 +101,9 @@ struct bis_options {
     int spmv_sellwin_rows = -1; // rows per lane of the sliced-ELL form: 1 or 2 (blocks of 256 or 512 rows; -1: default 2)
     int spmv_sellwin_pairs = -1; // 0: never the one-byte (column - row, value) pair codes
     int spmv_sellwin_joint = -1; // 0: never the 16-bit joint (slot, value) codes
+    int spmv_win8 = -1;        // window + sliced-ELL SpMV with the 8-byte values streamed (matrices without a dictionary form, or with spmv_valdict = 0): 0 off, 1 on where its plan applies (-1: default = on)
+    int spmv_win8_rows = -1;   // ... rows per lane: 1, 2 or 4 (blocks of 256, 512, 1024 rows; default 2)
+    int spmv_win8_depth = -1;  // ... chunks in flight per lane: 2, 3, 4 or 6 (default 4)
     int spmv_sellwin_masks = -1; // 0: never the per-row pair masks (fmt 4: 4 bytes per ROW where the matrix has at most 32 (column - row, value) pairs)
     int device_share = -1;  // k > 1: this device is shared by k processes that all run persistent grids (several ranks on one GPU in a test
                             // or rehearsal): kernels that need their whole grid resident keep to 1/k of the device
@@ -171,6 +174,9 @@ struct bis_mat {
     // x-window + sliced-ELL form of the dictionary kernel (bis_spmv_sell.hip); state as above
     struct bis_sellwin *sw = nullptr;
     int sw_state = 0;
+    // the same plan with the 8-byte values streamed (no dictionary needed): "win8", bis_spmv_sell.hip; state as above
+    struct bis_sellwin *sw8 = nullptr;
+    int sw8_state = 0;
     // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
     int32_t *blkf_row = nullptr;
     int64_t *blkf_nnz = nullptr;
@@ -315,6 +321,15 @@ int bis_spmv_sellwin_format(const bis_mat *A);
 bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y, int mode, const double *w,
                                    double *partials, const int *stop, int remap_arg, int grid);
 void bis_spmv_sellwin_drop(bis_mat *A);
+// window + sliced-ELL form with the 8-byte values streamed (bis_spmv_sell.hip, "win8")
+bis_status bis_spmv_win8_try(bis_ctx *ctx, bis_mat *A);
+int bis_spmv_win8_blocks(const bis_mat *A);
+int64_t bis_spmv_win8_slices(const bis_mat *A);
+int64_t bis_spmv_win8_partials(const bis_mat *A);
+int64_t bis_spmv_win8_bytes(const bis_mat *A);
+bis_status bis_spmv_win8_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y, int mode, const double *w,
+                                double *partials, const int *stop, int remap_arg, int grid);
+void bis_spmv_win8_drop(bis_mat *A);
 // try to build the packed-column stream of table t (0 plain, 1 fused); A->pk_state[t] tells the outcome
 bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t);
 // free row-block tables, packed streams and window structures (not the CRS arrays)

@@ -979,6 +979,7 @@ void bis_spmv_drop_valdict(bis_mat *A) {
     hipFree(A->rm_nnz); hipFree(A->rm_pk); hipFree(A->rm_seg);
     A->rm_nnz = nullptr; A->rm_pk = nullptr; A->rm_seg = nullptr; A->rm_state = 0; A->rm_blocks = 0;
     bis_spmv_sellwin_drop(A);
+    bis_spmv_win8_drop(A);
 }
 
 // the 256-row blocks of the lane-per-row form and their packed column stream; rm_state tells the outcome
@@ -1223,6 +1224,32 @@ static bis_status launch_sellwin(bis_ctx *ctx, const bis_mat *A, const SpmvArgs 
     return BIS_OK;
 }
 
+// window + sliced-ELL form with the 8-byte values streamed (bis_spmv_sell.hip, "win8"): for matrices the dictionary forms do not
+// serve (arbitrary values, or spmv_valdict = 0), where the plan applies; modes 0 and 1
+static bool win8_wanted() { return bis_opts().spmv_win8 != 0 && (bis_opts().spmv_variant < 0 || bis_opts().spmv_variant == 20); }
+static bis_status launch_win8(bis_ctx *ctx, const bis_mat *A, const SpmvArgs &a, const double *x, double *y, int mode,
+                              const double *w, double *partials, size_t partials_off, int *n_partials, bool *done) {
+    *done = false;
+    if (mode == 2 || !win8_wanted()) return BIS_OK;
+    if (bis_status st = bis_spmv_win8_try(ctx, const_cast<bis_mat *>(A))) return st;
+    const int nbr = bis_spmv_win8_blocks(A);
+    if (!nbr) return BIS_OK;
+    const int64_t n_slices = bis_spmv_win8_partials(A); // (one partial of the fused dot per wave)
+    if (mode == 1 && partials_off + (size_t)n_slices > ctx->partials_cap) {
+        ctx->err = "bis_spmv: partials buffer too small (internal)";
+        return BIS_ERR_INVALID;
+    }
+    const int remap_arg = remap_arg_for((nbr + 7) & ~7);
+    bis_prof_begin(ctx);
+    bis_status st = bis_spmv_win8_launch(ctx, A, x, y, mode, w, mode == 1 ? partials + partials_off : partials, a.stop,
+                                         remap_arg, grid_for_map(nbr, remap_arg));
+    bis_prof_end(ctx);
+    if (st != BIS_OK) return st;
+    if (mode == 1 && n_partials) *n_partials = (int)n_slices;
+    *done = true;
+    return BIS_OK;
+}
+
 // lane-per-row form of the dictionary kernel where the matrix qualifies (*done tells); mode 0 / 1 / 2 as in SpmvArgs
 static bis_status launch_rowmajor(bis_ctx *ctx, const bis_mat *A, const SpmvArgs &a, const double *x, double *y, int mode,
                                   const double *w, double *partials, size_t partials_off, int *n_partials, bool *done) {
@@ -1324,6 +1351,11 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
         if (bis_status st = launch_rowmajor(ctx, A, a, x, y, w ? 1 : 0, w, ctx->partials, partials_off, n_partials, &done)) return st;
         if (done) return BIS_OK;
     }
+    {
+        bool done = false;
+        if (bis_status st = launch_win8(ctx, A, a, x, y, w ? 1 : 0, w, ctx->partials, partials_off, n_partials, &done)) return st;
+        if (done) return BIS_OK;
+    }
     if (bis_opts().spmv_lds_pad > 0) a.lds_bytes += (size_t)bis_opts().spmv_lds_pad;
     bis_prof_begin(ctx);
     const bool ok = A->rp64 ? launch_by_id<int64_t>(spmv_variant(a), a)
@@ -1389,6 +1421,17 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
         if (A->rm_state == 1) f = A->vd_diag ? 3 : 2;
     }
     if (!f && a.vcode && !a.vd_rm_only && spmv_variant(a) == 20 && a.pk_mode == 1) f = 1;
+    if (!f && win8_wanted() && A->n_rows > 0) { // form 6: window + sliced ELL, 8-byte values + 2-byte window slots
+        if (bis_status st = bis_spmv_win8_try(ctx, const_cast<bis_mat *>(A))) return st;
+        if (bis_spmv_win8_blocks(A)) f = 6;
+    }
+    if (f == 6) {
+        if (col_bytes) *col_bytes = 2;
+        if (val_bytes) *val_bytes = 8;
+        if (n_dict) *n_dict = 0;
+        if (form) *form = 6;
+        return BIS_OK;
+    }
     if (col_bytes) *col_bytes = (f >= 4 && bis_spmv_sellwin_format(A) == 4) ? 0 : (f >= 4 && bis_spmv_sellwin_format(A) == 3) ? 1 : ((f >= 2 || a.pk_mode) ? 2 : 4); // 1: one byte per non-zero, the index of its (column - row, value) pair; 0: a 32-bit mask of pairs per ROW
     if (val_bytes) *val_bytes = f ? (f >= 4 && bis_spmv_sellwin_format(A) >= 2 ? 0 : 1) : 8; // 0: the value index shares the column code
     if (n_dict) *n_dict = f ? A->vd_n : 0;
@@ -1403,7 +1446,9 @@ bis_status bis_mat_spmv_streamed_bytes(bis_ctx *ctx, const bis_mat *A, int64_t *
     if (bis_status st = bis_mat_spmv_stream_info(ctx, A, &col_b, &val_b, &n_dict, &form)) return st;
     const int64_t rp = A->rp64 ? 8 : 4;
     int64_t b = 8 * A->n_cols + 8 * A->n_rows; // x once, y once
-    if (form >= 4) {
+    if (form == 6) {
+        b += bis_spmv_win8_bytes(A);
+    } else if (form >= 4) {
         b += bis_spmv_sellwin_bytes(A);
     } else if (form >= 2) {
         b += 3 * A->nnz + rp * (A->n_rows + 1) + (int64_t)A->rm_blocks * (A->rm_kind == 3 ? 128 : 32) + 2048;

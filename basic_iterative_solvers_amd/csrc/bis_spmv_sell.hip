@@ -1232,3 +1232,341 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
     }
     return BIS_OK;
 }
+
+// =====================================================================================================================
+// win8: the SAME window + sliced-ELL plan for matrices with ARBITRARY values (round 5).  Per non-zero the kernel streams the
+// 8-byte CRS value and a 2-byte window slot -- 10 bytes, like the packed row-block kernel of bis_spmv.hip -- but x comes
+// from the block's LDS window (every entry once per block, by LDS-DMA) instead of one 8-byte gather per non-zero through
+// the texture path, a lane owns a row (no product staging in LDS, no row_ptr, no second pass), and the stream is laid out
+// in the order the lanes consume it: a chunk = 4 entries of each of the 64 rows of a slice = 2560 contiguous bytes
+// [64 x (4 x 16-bit slot)][64 x 2 values][64 x 2 values], read with one 8-byte and two 16-byte non-temporal loads per lane.
+// Entry j of a row is entry j of the CRS row; product and sum are rounded separately, in CRS order: y is bit-identical to
+// the other kernels'.  Padding: value 1.0 at the slot that holds -0.0.  The CRS arrays stay authoritative (the stream is a
+// lossless re-layout of val, built on the device at the first SpMV and dropped when values change).
+// Usable by any matrix whose blocks of 256 R rows read a few contiguous runs of x (banded / stencil / RCM-ordered meshes)
+// and whose rows within a 64-row slice have similar lengths (<= 30 % padding).
+namespace {
+
+constexpr int kW8ChunkBytes = 2560;
+
+template <typename RP>
+__global__ __launch_bounds__(256) void w8_fill_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                      int64_t n_rows, int R, const int32_t *__restrict__ hdr,
+                                                      const int64_t *__restrict__ slice_chunk0, unsigned char *__restrict__ stream) {
+    __shared__ int g0s[kSwRuns], rk[kSwRuns];
+    __shared__ int nr_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < kSwRuns) {
+        g0s[tid] = hdr[(size_t)b * 64 + tid];
+        const int w2 = hdr[(size_t)b * 64 + 32 + tid];
+        rk[tid] = w2 & 0xffff;
+        const unsigned long long m = __ballot((w2 >> 16) != 0);
+        if (tid == 0) nr_s = __popcll(m);
+    }
+    __syncthreads();
+    const int nr = nr_s;
+    for (int rr = 0; rr < R; ++rr) {
+        const int64_t slice = ((int64_t)b * 4 + wv) * R + rr;
+        const int64_t r = slice * 64 + lane;
+        int64_t rs = 0;
+        int len = 0;
+        if (r < n_rows) {
+            rs = (int64_t)row_ptr[r];
+            len = (int)((int64_t)row_ptr[r + 1] - rs);
+        }
+        const int64_t c0 = slice_chunk0[slice];
+        const int nch = (int)(slice_chunk0[slice + 1] - c0);
+        for (int c = 0; c < nch; ++c) {
+            unsigned cc[4];
+            double vv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * c + q;
+                cc[q] = 0;      // the -0.0 slot
+                vv[q] = 1.0;    // 1.0 * -0.0 = -0.0: acc + -0.0 == acc for every acc
+                if (j < len) {
+                    const int ci = col[rs + j];
+                    const int g = ci >> 3;
+                    int lo = 0, hi = nr - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (g0s[mid] <= g) lo = mid; else hi = mid - 1;
+                    }
+                    cc[q] = (unsigned)(2 + (rk[lo] + (g - g0s[lo])) * 8 + (ci & 7)) * 8u; // byte offset of the slot behind the window's base
+                    vv[q] = val[rs + j];
+                }
+            }
+            unsigned char *p = stream + (size_t)(c0 + c) * kW8ChunkBytes;
+            *reinterpret_cast<uint2 *>(p + lane * 8) = make_uint2(cc[0] | cc[1] << 16, cc[2] | cc[3] << 16);
+            *reinterpret_cast<double2 *>(p + 512 + lane * 16) = make_double2(vv[0], vv[1]);
+            *reinterpret_cast<double2 *>(p + 1536 + lane * 16) = make_double2(vv[2], vv[3]);
+        }
+    }
+}
+
+typedef double w8_v2d __attribute__((ext_vector_type(2)));
+typedef unsigned w8_v2u __attribute__((ext_vector_type(2)));
+struct W8Chunk { w8_v2u code; w8_v2d v0, v1; };
+
+// one chunk of the stream for this lane: three non-temporal loads (the stream is read once per product)
+__device__ __forceinline__ W8Chunk w8_load(const unsigned char *__restrict__ stream, int64_t c, int lane) {
+    const unsigned char *p = stream + (size_t)c * kW8ChunkBytes;
+    W8Chunk ch;
+    ch.code = __builtin_nontemporal_load(reinterpret_cast<const w8_v2u *>(p + lane * 8));
+    ch.v0 = __builtin_nontemporal_load(reinterpret_cast<const w8_v2d *>(p + 512 + lane * 16));
+    ch.v1 = __builtin_nontemporal_load(reinterpret_cast<const w8_v2d *>(p + 1536 + lane * 16));
+    return ch;
+}
+
+// acc += v_q * window[slot_q], q = 0..3, products and sums rounded separately (the CRS kernels' arithmetic)
+__device__ __forceinline__ void w8_consume(const unsigned char *win, const W8Chunk &ch, double &acc) {
+#pragma clang fp contract(off)
+    const double x0 = *reinterpret_cast<const double *>(win + (ch.code.x & 0xffffu));
+    const double x1 = *reinterpret_cast<const double *>(win + (ch.code.x >> 16));
+    const double x2 = *reinterpret_cast<const double *>(win + (ch.code.y & 0xffffu));
+    const double x3 = *reinterpret_cast<const double *>(win + (ch.code.y >> 16));
+    const double p0 = ch.v0.x * x0, p1 = ch.v0.y * x1, p2 = ch.v1.x * x2, p3 = ch.v1.y * x3;
+    acc = acc + p0;
+    acc = acc + p1;
+    acc = acc + p2;
+    acc = acc + p3;
+}
+
+// MODE 0: y = A x.  MODE 1: also partials[4 b + wave] = sum over the wave's rows of y[r] w[r] (CG's (Ap, p)).
+// A wave owns the R consecutive slices slice0 .. slice0 + R - 1; their chunks are ONE contiguous range of the stream (the chunk
+// offsets are a prefix sum), walked with a ring of D chunks in flight per lane: the chunk D places ahead is requested as soon
+// as a ring entry has been consumed, so the stream never waits for the arithmetic, and the first D chunks are requested before
+// the window is (they do not need it).  LDS: 16 bytes (the -0.0 slot), then the window.
+template <int MODE, int R, int D>
+__global__ __launch_bounds__(256) void spmv_win8_kernel(
+    const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
+    double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
+    const unsigned char *__restrict__ stream, int x_al16, const int32_t *__restrict__ own_rank) {
+    if (stop && stop[1]) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int b = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
+                                : (remap_arg < -1 ? xcd_group_remap(blockIdx.x, -remap_arg) : (int)blockIdx.x);
+    if (b >= n_blocks) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = hdr[(size_t)b * 64 + lane];
+    const int64_t slice0 = ((int64_t)b * 4 + wv) * R;
+    // chunk boundaries of the wave's slices: lane r holds slice_chunk0[slice0 + r], r <= R
+    const int64_t my_bnd = slice_chunk0[slice0 + min(lane, R)];
+    auto bnd = [&](int r) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)my_bnd, r);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)my_bnd >> 32), r);
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
+    const int64_t C0 = bnd(0), C1 = bnd(R);
+    const int64_t c_last = max(C1 - 1, C0); // (the stream ends with one spare chunk: an empty wave reads it)
+    W8Chunk ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = w8_load(stream, min(C0 + d, c_last), lane);
+    // MODE 1: the dot's operand.  own_rank != nullptr: w is x at the rows' own columns (CG: w = x = p) -- where the block's window
+    // holds them side by side (own >= 0) the operand comes from LDS behind the barrier instead of a second global read of p
+    double wr[R];
+    int own = -1;
+    if (MODE == 1 && own_rank) own = own_rank[b];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = (slice0 + r) * 64 + lane;
+        wr[r] = (MODE == 1 && own < 0 && row < n_rows) ? w[row] : 0.0;
+    }
+    if (tid == 0) *reinterpret_cast<double *>(lds) = -0.0;
+    {   // window: the runs of 8-column granules, 16-byte pieces by LDS-DMA (as spmv_sellwin_kernel)
+        const int n_runs = __popcll(__ballot(lane >= 32 && (hw >> 16) != 0));
+        unsigned char *win = lds + 16;
+        for (int k = 0; k < n_runs; ++k) {
+            const int g0 = __builtin_amdgcn_readlane(hw, k);
+            const int w2 = __builtin_amdgcn_readlane(hw, 32 + k);
+            const int rank = w2 & 0xffff, n_pieces = (w2 >> 16) * 4;
+            const int j = (wv + k) & 3;
+            const int p = j * 64 + lane;
+            const int64_t c = (int64_t)g0 * 8 + 2 * p;
+            unsigned char *dst = win + (size_t)rank * 64 + (size_t)j * 1024;
+            if (p < n_pieces) {
+                if (x_al16 && c + 1 < n_cols) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + c),
+                                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+                } else {
+                    double2 v;
+                    v.x = c < n_cols ? x[c] : 0.0;
+                    v.y = c + 1 < n_cols ? x[c + 1] : 0.0;
+                    *reinterpret_cast<double2 *>(dst + lane * 16) = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (MODE == 1 && own >= 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) wr[r] = *reinterpret_cast<const double *>(lds + 16 + ((size_t)own * 8 + (wv * R + r) * 64 + lane) * 8);
+    }
+    double dot_acc = 0.0; // MODE 1: sum over the wave's slices of y[row] w[row] (one partial per WAVE)
+    // the walk over [C0, C1): ring[d] holds chunk c whenever (c - C0) % D == d, so the ring index is a compile-time constant in
+    // the unrolled round; slice rr of the wave ends at chunk e[rr] (an empty slice: e[rr] == e[rr - 1]).  All slice indices
+    // are compile-time constants too (a run-time index put wr[] into scratch memory).
+    int64_t e[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) e[rr] = bnd(rr + 1);
+    int64_t c = C0;
+    int next = 0; // the slice being summed (wave-uniform)
+    double acc = 0.0;
+#define W8_END_SLICES()                                                                    \
+    _Pragma("unroll") for (int rr = 0; rr < R; ++rr)                                       \
+        if (rr == next && c == e[rr]) {                                                    \
+            const int64_t row = (slice0 + rr) * 64 + lane;                                 \
+            if (row < n_rows) y[row] = acc;                                                \
+            if (MODE == 1) dot_acc += row < n_rows ? acc * wr[rr] : 0.0;                   \
+            acc = 0.0;                                                                     \
+            ++next;                                                                        \
+        }
+    W8_END_SLICES()
+    while (c < C1) { // (wave-uniform)
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (c < C1) {
+                const W8Chunk cur = ring[d];
+                ring[d] = w8_load(stream, min(c + D, c_last), lane);
+                w8_consume(lds, cur, acc);
+                ++c;
+                W8_END_SLICES()
+            }
+        }
+    }
+#undef W8_END_SLICES
+    if (MODE == 1) {
+        const double t = wave_sum(dot_acc);
+        if (lane == 0) partials[(size_t)b * 4 + wv] = t;
+    }
+}
+
+} // namespace
+
+void bis_spmv_win8_drop(bis_mat *A) {
+    if (A->sw8) {
+        hipFree(A->sw8->hdr); hipFree(A->sw8->slice_chunk0); hipFree(A->sw8->own_rank); hipFree(A->sw8->codes);
+        delete A->sw8;
+        A->sw8 = nullptr;
+    }
+    A->sw8_state = 0;
+}
+
+int bis_spmv_win8_blocks(const bis_mat *A) { return A->sw8_state == 1 ? A->sw8->n_blocks : 0; }
+int64_t bis_spmv_win8_slices(const bis_mat *A) { return A->sw8_state == 1 ? A->sw8->n_slices : 0; }
+int64_t bis_spmv_win8_partials(const bis_mat *A) { return A->sw8_state == 1 ? (int64_t)A->sw8->n_blocks * 4 : 0; } // fused dot: one per wave
+// bytes of the form's own arrays one launch reads: the stream (with its padding), block headers, slice offsets
+int64_t bis_spmv_win8_bytes(const bis_mat *A) {
+    if (A->sw8_state != 1) return 0;
+    return A->sw8->total_chunks * (int64_t)kW8ChunkBytes + (int64_t)A->sw8->n_blocks * 256 + 8 * (A->sw8->n_slices + 1);
+}
+
+#define W8_CHECK(call)                                                         \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) {                                                \
+            (void)hipGetLastError();                                           \
+            hipFree(slice_chunks); hipFree(tmp);                               \
+            bis_spmv_win8_drop(A);                                             \
+            A->sw8_state = -1;                                                 \
+            if (e_ == hipErrorOutOfMemory) return BIS_OK; /* the gather kernel stays */ \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);      \
+            return BIS_ERR_HIP;                                                \
+        }                                                                      \
+    } while (0)
+
+// Build the form (A->sw8_state: 1 usable, -1 does not apply).  Rows per lane: option spmv_win8_rows (1, 2, 4), default 2 for
+// matrices of at least half a million rows.
+bis_status bis_spmv_win8_try(bis_ctx *ctx, bis_mat *A) {
+    if (A->sw8_state != 0) return BIS_OK;
+    A->sw8_state = -1;
+    if (A->n_rows == 0 || A->nnz == 0 || A->n_cols >= ((int64_t)1 << 31) - 16) return BIS_OK;
+    // default 4 rows per lane (blocks of 1024 rows): HPCG-256 0.78 ms against 0.86 with 2 and 1.20 with 1 -- the larger the block, the
+    // fewer times an x entry is copied into some block's window (tools/win8_probe.py, profiles/r05_c_win8_probe.log)
+    int R = bis_opts().spmv_win8_rows > 0 ? std::min(bis_opts().spmv_win8_rows, 4) : 4;
+    if (R == 3) R = 2;
+    while (R > 1 && A->n_rows < (int64_t)kSwRows * R * 1024) R >>= 1;
+    const int64_t nb64 = (A->n_rows + (int64_t)kSwRows * R - 1) / ((int64_t)kSwRows * R);
+    if (nb64 > (int64_t)1 << 26) return BIS_OK;
+    const int nb = (int)nb64;
+    bis_sellwin *sw = new bis_sellwin;
+    A->sw8 = sw;
+    sw->n_blocks = nb;
+    sw->R = R;
+    sw->n_slices = (int64_t)nb * 4 * R;
+    sw->fmt = 5;
+    int32_t *slice_chunks = nullptr;
+    void *tmp = nullptr;
+    int *status = (int *)ctx->counters + 52;
+    W8_CHECK(hipMalloc(&sw->hdr, sizeof(int32_t) * 64 * (size_t)nb));
+    W8_CHECK(hipMalloc(&sw->own_rank, sizeof(int32_t) * (size_t)nb));
+    W8_CHECK(hipMemsetAsync(sw->own_rank, 0xFF, sizeof(int32_t) * (size_t)nb, ctx->stream)); // (blocks the plan leaves early: -1)
+    W8_CHECK(hipMalloc(&slice_chunks, sizeof(int32_t) * (size_t)(sw->n_slices + 1)));
+    W8_CHECK(hipMalloc(&sw->slice_chunk0, sizeof(int64_t) * (size_t)(sw->n_slices + 1)));
+    W8_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream));
+    W8_CHECK(hipMemsetAsync(status + 5, 0, sizeof(int), ctx->stream));
+    W8_CHECK(hipMemsetAsync(slice_chunks, 0, sizeof(int32_t) * (size_t)(sw->n_slices + 1), ctx->stream));
+    W8_CHECK(hipMemsetAsync(sw->hdr, 0, sizeof(int32_t) * 64 * (size_t)nb, ctx->stream));
+    if (A->rp64) hipLaunchKernelGGL(sw_plan_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->n_rows, R, kSwMaxGran, A->view_row0, sw->hdr, slice_chunks, sw->own_rank, status);
+    else hipLaunchKernelGGL(sw_plan_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->n_rows, R, kSwMaxGran, A->view_row0, sw->hdr, slice_chunks, sw->own_rank, status);
+    W8_CHECK(hipGetLastError());
+    int h[2] = {0, 0};
+    W8_CHECK(hipMemcpyAsync(h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    const int64_t ns1 = sw->n_slices + 1;
+    hipLaunchKernelGGL(sw_widen_kernel, dim3((unsigned)((ns1 + 255) / 256)), dim3(256), 0, ctx->stream, slice_chunks, sw->slice_chunk0, ns1);
+    W8_CHECK(hipGetLastError());
+    size_t tmp_bytes = 0;
+    W8_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, sw->slice_chunk0, sw->slice_chunk0, (int64_t)0, (size_t)ns1, rocprim::plus<int64_t>(), ctx->stream));
+    W8_CHECK(hipMalloc(&tmp, tmp_bytes));
+    W8_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, sw->slice_chunk0, sw->slice_chunk0, (int64_t)0, (size_t)ns1, rocprim::plus<int64_t>(), ctx->stream));
+    int64_t total = 0;
+    W8_CHECK(hipMemcpyAsync(&total, sw->slice_chunk0 + sw->n_slices, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    W8_CHECK(hipStreamSynchronize(ctx->stream));
+    hipFree(tmp); tmp = nullptr;
+    hipFree(slice_chunks); slice_chunks = nullptr;
+    sw->total_chunks = total;
+    sw->max_gran = h[1];
+    // not representable (more than 32 runs / 60 KiB of window in some block), or more than 30 % of padding: the gather kernel stays
+    if (h[0] || (double)total * 256.0 > 1.3 * (double)A->nnz + 256.0 * 4 * 64) {
+        if (getenv("BIS_WIN8_STATS")) fprintf(stderr, "win8 plan (R = %d): %s, %.1f %% padding: not used\n", R, h[0] ? "window not representable" : "representable", 100.0 * ((double)total * 256.0 / (double)A->nnz - 1.0));
+        bis_spmv_win8_drop(A);
+        A->sw8_state = -1;
+        return BIS_OK;
+    }
+    unsigned char *stream = nullptr;
+    W8_CHECK(hipMalloc(&stream, (size_t)kW8ChunkBytes * (size_t)(total + 1)));
+    sw->codes = reinterpret_cast<uint32_t *>(stream);
+    W8_CHECK(hipMemsetAsync(stream + (size_t)total * kW8ChunkBytes, 0, kW8ChunkBytes, ctx->stream));
+    if (A->rp64) hipLaunchKernelGGL(w8_fill_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->val, A->n_rows, R, sw->hdr, sw->slice_chunk0, stream);
+    else hipLaunchKernelGGL(w8_fill_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->val, A->n_rows, R, sw->hdr, sw->slice_chunk0, stream);
+    W8_CHECK(hipGetLastError());
+    if (getenv("BIS_WIN8_STATS")) fprintf(stderr, "win8 plan (R = %d): %d blocks, window <= %d granules (%zu bytes), %.1f %% padding: used\n", R, nb, sw->max_gran, (size_t)(2 + 8 * sw->max_gran) * 8, 100.0 * ((double)total * 256.0 / (double)A->nnz - 1.0));
+    A->sw8_state = 1;
+    return BIS_OK;
+}
+#undef W8_CHECK
+
+bis_status bis_spmv_win8_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y, int mode, const double *w,
+                                double *partials, const int *stop, int remap_arg, int grid) {
+    const bis_sellwin *sw = A->sw8;
+    const int x_al16 = ((uintptr_t)x & 15) == 0;
+    const size_t lds = (size_t)(2 + 8 * sw->max_gran) * 8;
+    const unsigned char *stream = reinterpret_cast<const unsigned char *>(sw->codes);
+    const int32_t *own = (mode == 1 && w == x + A->view_row0 && x_al16) ? sw->own_rank : nullptr; // the fused dot's w is x itself (CG: p)
+    // chunks requested ahead per lane.  1024-row blocks: 1 where the slices are uniform (HPCG-256 in the CG loop 0.758 ms; 2: 0.771,
+    // 3: 0.764; HPCG-512 6.16 / 6.70 / 6.38), 2 with ragged rows (fem:80,80,81: 0.211 ms; 1: 0.221, 3: 0.221); 512-row blocks: 3
+    // (HPCG-256 0.861; 2: 0.945, 4: 1.030).  The waves of the other workgroups on the CU cover the rest of the latency.
+    const bool ragged = (double)sw->total_chunks * 256.0 > 1.08 * (double)A->nnz;
+    const int depth = bis_opts().spmv_win8_depth > 0 ? bis_opts().spmv_win8_depth : (sw->R == 4 ? (ragged ? 2 : 1) : 3);
+#define W8_L3(MODE, RR, DD) hipLaunchKernelGGL((spmv_win8_kernel<MODE, RR, DD>), dim3(grid), dim3(256), lds, ctx->stream, x, y, A->n_rows, A->n_cols, \
+                                               sw->n_blocks, remap_arg, w, partials, stop, sw->hdr, sw->slice_chunk0, stream, x_al16, own)
+#define W8_L2(MODE, RR) do { if (depth <= 1) W8_L3(MODE, RR, 1); else if (depth == 2) W8_L3(MODE, RR, 2); else if (depth == 3) W8_L3(MODE, RR, 3); else if (depth <= 5) W8_L3(MODE, RR, 4); else W8_L3(MODE, RR, 6); } while (0)
+#define W8_L1(MODE) do { if (sw->R == 4) W8_L2(MODE, 4); else if (sw->R == 2) W8_L2(MODE, 2); else W8_L2(MODE, 1); } while (0)
+    if (mode == 1) W8_L1(1); else W8_L1(0);
+#undef W8_L1
+#undef W8_L2
+#undef W8_L3
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    return BIS_OK;
+}

@@ -44,7 +44,7 @@ def r0_closed_form(matrix, shift, n1):
 
 
 KERNELS = ("spmv_rowblock_kernel", "spmv_rowblock_vd_kernel", "spmv_rowmajor_vd_kernel", "spmv_rowmajor_vd_kernel",
-           "spmv_sellwin_kernel", "spmv_sellwin_kernel")
+           "spmv_sellwin_kernel", "spmv_sellwin_kernel", "spmv_win8_kernel")
 
 
 class _Env:

@@ -150,7 +150,7 @@ def measured_stream(ctx, N):
 
 
 KERNEL_OF_FORM = ("spmv_rowblock_kernel", "spmv_rowblock_vd_kernel", "spmv_rowmajor_vd_kernel", "spmv_rowmajor_vd_kernel",
-                  "spmv_sellwin_kernel", "spmv_sellwin_kernel")
+                  "spmv_sellwin_kernel", "spmv_sellwin_kernel", "spmv_win8_kernel")
 
 
 def stream_format(A):

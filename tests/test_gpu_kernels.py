@@ -379,16 +379,21 @@ def hpcg_full_size_properties(ctx, n1, cg_iters):
     # the library's default stream format for this matrix (round 4: 32 bits per row, the row-mask kernel) against the kernel that
     # streams the CRS value array, on a second copy of the operator: y bit for bit
     assert dA.spmv_stream_info()[:2] == (0, 0) and dA.spmv_stream_info()[3] == 4
-    ctx.set_option("spmv_valdict", 0)
-    try:
-        dB = ctx.gen_hpcg(n1)
-        ctx.spmv(dB, du, y)
-        assert dB.spmv_stream_info()[1:] == (8, 0, 0)
-    finally:
-        ctx.set_option("spmv_valdict", -1)
-    ctx.subtract_vectors(y, y, yu, 1.0)
-    assert ctx.euclidean_vec_norm(y) == 0.0
-    dB.free()
+    # ... both kernels that stream 8-byte values: the window + sliced-ELL form (win8, the default without a dictionary) and the
+    # row-block kernel on the CRS arrays in place (spmv_win8 = 0)
+    for w8, form in ((-1, 6), (0, 0)):
+        ctx.set_option("spmv_valdict", 0)
+        ctx.set_option("spmv_win8", w8)
+        try:
+            dB = ctx.gen_hpcg(n1)
+            ctx.spmv(dB, du, y)
+            assert dB.spmv_stream_info()[1:] == (8, 0, form)
+        finally:
+            ctx.set_option("spmv_valdict", -1)
+            ctx.set_option("spmv_win8", -1)
+        ctx.subtract_vectors(y, y, yu, 1.0)
+        assert ctx.euclidean_vec_norm(y) == 0.0
+        dB.free()
     # symmetry: (Au, v) == (u, Av)
     a, b2 = ctx.dot(yu, dv), ctx.dot(du, yv)
     assert abs(a - b2) <= 1e-12 * max(abs(a), 1.0) * 10
@@ -1125,6 +1130,7 @@ def test_spmv_value_dictionary(ctx, oracle, form, rp64, no_sellwin):
     dictionary, unless some row holds two diagonal entries."""
     rng = np.random.default_rng(40 + form)
     ctx.set_option("force_rp64", rp64)
+    ctx.set_option("spmv_win8", 0)  # (the 8-byte baseline here is the row-block kernel on the CRS arrays; win8: tests/test_gpu_win8.py)
     try:
         dup = oracle.gen_anderson(9, W=5.0, shift=3.0)
         dup = CRS(dup.n_rows, dup.row_ptr, dup.col.copy(), dup.val)
@@ -1177,6 +1183,7 @@ def test_spmv_value_dictionary(ctx, oracle, form, rp64, no_sellwin):
     finally:
         ctx.set_option("spmv_valdict", -1)
         ctx.set_option("force_rp64", -1)
+        ctx.set_option("spmv_win8", -1)
 
 
 @pytest.mark.parametrize("form", [1, 2])
@@ -1188,6 +1195,7 @@ def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form, no_se
     A = oracle.gen_hpcg(16)
     n = A.n_rows
     out = {}
+    ctx.set_option("spmv_win8", 0)  # (the 8-byte baseline here is the row-block kernel on the CRS arrays)
     try:
         for mode in (0, form):
             ctx.set_option("spmv_valdict", mode)
@@ -1222,6 +1230,7 @@ def test_value_dictionary_in_fused_cg_and_colour_sweeps(ctx, oracle, form, no_se
                 assert np.array_equal(out[0][k], out[form][k]), k
     finally:
         ctx.set_option("spmv_valdict", -1)
+        ctx.set_option("spmv_win8", -1)
 
 
 def test_value_dictionary_kernel_selection_and_shapes(ctx, oracle, no_sellwin):
