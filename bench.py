@@ -241,10 +241,12 @@ def crs_value_stream_record(leg):
                          "algorithmic_frac": r["frac"], "avg_launch_ms": r["avg_launch_ms"], "launches": r["launches"]}}
 
 
-def cg_leg(ctx, A, b, x, D, steps, warmup, traffic_path, size, valdict=None):
+def cg_leg(ctx, A, b, x, D, steps, warmup, traffic_path, size, valdict=None, win8=None):
     """`steps` timed CG iterations after `warmup` on (A, b, x = 0.1); valdict=0: with the value dictionary off (the
-    kernel streams the 8-byte CRS values: SURVEY 8d's 'CRS SpMV'), None: the library's default stream format."""
+    kernel streams the 8-byte CRS values: SURVEY 8d's 'CRS SpMV'), None: the library's default stream format; win8=0: the
+    row-block kernel on the CRS arrays in place instead of the window + sliced-ELL re-layout of the values."""
     ctx.set_option("spmv_valdict", -1 if valdict is None else valdict)
+    ctx.set_option("spmv_win8", -1 if win8 is None else win8)
     try:
         ctx.init_vector(x, 0.1)
         cg = ctx.cg(A, b, x, D)
@@ -265,9 +267,16 @@ def cg_leg(ctx, A, b, x, D, steps, warmup, traffic_path, size, valdict=None):
         roof = spmv_roofline(A, avg_s, launches, traffic_path, size)
     finally:
         ctx.set_option("spmv_valdict", -1)
+        ctx.set_option("spmv_win8", -1)
     return {"steps": steps, "warmup": warmup, "cg_iterations_per_s": steps / secs, "ms_per_step": 1e3 * secs / steps,
             "spmv_avg_launch_ms": avg_s * 1e3, "spmv_frac_of_peak": roof["frac"], "roofline": roof,
             "residual_r0": r0, "residual_history": [float(h) for h in hist]}
+
+
+IN_PLACE_NOTE = ("the same loop with the row-block kernel reading the CRS val array and the packed column codes IN PLACE (x gathered through "
+                 "L1 / L2): round 4's headline kernel; bit-identical y")
+W8_NOTE = ("8-byte CRS values + 2-byte window slots streamed in sliced-ELL order (a lossless re-layout of the CRS arrays built on the "
+           "device), x window of each 1024-row block in LDS by LDS-DMA")
 
 
 def target_512(ctx, steps=10, warmup=3):
@@ -287,6 +296,11 @@ def target_512(ctx, steps=10, warmup=3):
     rec.update(leg)
     rec["residual_last"] = h1[-1]
     rec["crs_value_stream"] = crs_value_stream_record(leg)
+    inp = cg_leg(ctx, A, b, x, None, steps, warmup, traffic_file(n1), n1, valdict=0, win8=0)
+    h3 = inp.pop("residual_history")
+    inp["note"] = IN_PLACE_NOTE
+    inp["history_max_dev_over_r0_vs_headline"] = max(abs(a - c) for a, c in zip(h1, h3)) / h1[0]
+    rec["crs_arrays_in_place"] = inp
     cmp_ = cg_leg(ctx, A, b, x, None, steps, warmup, traffic_file(n1), n1)
     h2 = cmp_.pop("residual_history")
     cmp_["note"] = "the library's default stream format for this matrix (lossless re-encoding, bit-identical y)"
@@ -706,8 +720,8 @@ def main():
         "config": {"workload": f"HPCG {n1}^3 27-point, -cg" +
                                (" -p j" if args.precond == "j" else "") +
                                ", b=1 x0=0.1, fused device schedule, " +
-                               ("CRS values streamed (8 B per non-zero)" if roof["spmv_stream"]["val_bytes"] == 8
-                                else "default (compressed) stream format"),
+                               ("CRS values streamed (8 B per non-zero" + ("; " + W8_NOTE if roof["spmv_stream"]["form"] == 6 else "") + ")"
+                                if roof["spmv_stream"]["val_bytes"] == 8 else "default (compressed) stream format"),
                    "rows": N, "nnz": nnz, "partition": "1 GPU"},
         "spmv_gflops": 2.0 * nnz / spmv_avg_s / 1e9,
         # the fused schedule's algorithmic bytes per iteration (12 nnz + 20 N + the two vector passes) per second
@@ -722,6 +736,13 @@ def main():
     if roof["spmv_stream"]["val_bytes"] == 8:  # the headline once more, priced on the PMC traffic (see crs_value_stream_record)
         out["crs_value_stream"] = crs_value_stream_record({"cg_iterations_per_s": its, "ms_per_step": 1e3 * secs / args.steps,
                                                            "spmv_avg_launch_ms": spmv_avg_s * 1e3, "roofline": roof})
+    if args.headline != "default" and roof["spmv_stream"]["form"] == 6:
+        leg = cg_leg(ctx, A, b, x, D, min(args.steps, 50), min(args.warmup, 5), args.traffic_json or traffic_file(n1), n1, valdict=0, win8=0)
+        h3 = np.array(leg.pop("residual_history"))
+        m3 = min(len(h3), len(hist))
+        leg["history_max_dev_over_r0_vs_timed_run"] = float(np.max(np.abs(h3[:m3] - np.array(hist[:m3]))) / h3[0])
+        leg["note"] = IN_PLACE_NOTE
+        out["crs_arrays_in_place"] = leg
     if args.headline != "default":
         # the same loop on the same arrays with the library's default stream format for this matrix
         leg = cg_leg(ctx, A, b, x, D, min(args.steps, 50), min(args.warmup, 5), args.traffic_json or traffic_file(n1), n1)

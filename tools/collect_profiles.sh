@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-target-512"
+B="python3 $R/bench.py --no-cpu-baseline --no-target-512 --no-sweeps --no-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r -- $B --steps 50 --warmup 5 > $O/bench_under_rocprof.json 2> $O/trace.err &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o r -- $B --steps 5 --warmup 1 > $O/fetch.json 2> $O/fetch.err &&
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o r -- $B --steps 5 --warmup 1 > $O/write.json 2> $O/write.err &&
