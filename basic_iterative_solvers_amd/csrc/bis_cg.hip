@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, double *sc, in
                                                        double *__restrict__ r,
                                                        double *__restrict__ z,
                                                        double *partials, size_t stride, unsigned *counter,
-                                                       double *hist, int hist_cap, int nt_tmp) {
+                                                       double *hist, int hist_cap, int nt_tmp, int nt_r) {
     __shared__ double lds[kT / 64];
     __shared__ bool last;
     if (flags[1]) return;
@@ -172,7 +172,11 @@ __global__ __launch_bounds__(kT) void cg_update_kernel(int64_t n, double *sc, in
             const cg_v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const cg_v2d_t *>(t2 + i));
             tv = make_double2(v.x, v.y);
         } else tv = t2[i];
-        double2 rv = r2[i], zv;
+        double2 rv, zv;
+        if (nt_r) { // (option cg_nt_x = 3: every input stream of the pass read non-temporally, as the BLAS-1 kernels do)
+            const cg_v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const cg_v2d_t *>(r2 + i));
+            rv = make_double2(v.x, v.y);
+        } else rv = r2[i];
         rv.x = fma(-alpha, tv.x, rv.x);        // cg.hpp:31
         rv.y = fma(-alpha, tv.y, rv.y);
         r2[i] = rv;
@@ -231,7 +235,7 @@ __global__ void cg_book_kernel(double *sc, int *flags, double *hist, int hist_ca
 // less per iteration than updating x in pass B); p = z + beta p (cg.hpp:52; None: z == r).
 // `it` = the iteration this launch belongs to: when the stop test fired in THIS iteration the x
 // update still runs (the reference updates x before it samples the residual), later launches are no-ops.
-template <bool NT>
+template <bool NT, bool NT_ALL = false>
 __global__ __launch_bounds__(kT) void cg_p_update_kernel(int64_t n, const double *__restrict__ sc,
                                                          const int *__restrict__ flags, int it,
                                                          const double *__restrict__ z,
@@ -244,8 +248,12 @@ __global__ __launch_bounds__(kT) void cg_p_update_kernel(int64_t n, const double
     double2 *p2 = reinterpret_cast<double2 *>(p);
     double2 *x2 = reinterpret_cast<double2 *>(x);
     for (int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x; i < n2; i += gs) {
-        const double2 zv = z2[i];
-        double2 pv = p2[i], xv;
+        double2 zv, pv, xv;
+        if (NT_ALL) { // (option cg_nt_x = 3)
+            const cg_v2d_t a = __builtin_nontemporal_load(reinterpret_cast<const cg_v2d_t *>(z2 + i));
+            const cg_v2d_t c = __builtin_nontemporal_load(reinterpret_cast<const cg_v2d_t *>(p2 + i));
+            zv = make_double2(a.x, a.y); pv = make_double2(c.x, c.y);
+        } else { zv = z2[i]; pv = p2[i]; }
         if (NT) { // x is touched here and nowhere else in the iteration: keep it out of the caches p, r and A p live in
             const cg_v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const cg_v2d_t *>(x2 + i));
             xv = make_double2(v.x, v.y);
@@ -416,7 +424,7 @@ static bis_status cg_enqueue_iteration(bis_ctx *ctx, bis_cg *cg, int g, int it) 
 #define BIS_CG_UPDATE(J, D)                                                                                  \
     hipLaunchKernelGGL((cg_update_kernel<J, D>), dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags,    \
                        cg->tmp, cg->A_D, cg->r, cg->z, ctx->partials, (size_t)kMaxReduceBlocks,              \
-                       cg->counters + 1, cg->hist, cg->hist_cap, bis_opts().cg_nt_x != 0 && bis_opts().cg_nt_x != 2)
+                       cg->counters + 1, cg->hist, cg->hist_cap, bis_opts().cg_nt_x != 0 && bis_opts().cg_nt_x != 2, bis_opts().cg_nt_x == 3)
     if (cg->pc >= 0) BIS_CG_UPDATE(false, true); // r update and (r,r) only; z and (r,z) follow below
     else if (cg->dist) { if (cg->A_D) BIS_CG_UPDATE(true, true); else BIS_CG_UPDATE(false, true); }
     else { if (cg->A_D) BIS_CG_UPDATE(true, false); else BIS_CG_UPDATE(false, false); }
@@ -434,7 +442,8 @@ static bis_status cg_enqueue_iteration(bis_ctx *ctx, bis_cg *cg, int g, int it) 
         if (st != BIS_OK) return st;
         hipLaunchKernelGGL(cg_book_kernel, dim3(1), dim3(64), 0, ctx->stream, cg->sc, cg->flags, cg->hist, cg->hist_cap);
     }
-    if (bis_opts().cg_nt_x != 0) hipLaunchKernelGGL(cg_p_update_kernel<true>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags, it, cg->z, cg->x, cg->p);
+    if (bis_opts().cg_nt_x == 3) hipLaunchKernelGGL((cg_p_update_kernel<true, true>), dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags, it, cg->z, cg->x, cg->p);
+    else if (bis_opts().cg_nt_x != 0) hipLaunchKernelGGL(cg_p_update_kernel<true>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags, it, cg->z, cg->x, cg->p);
     else hipLaunchKernelGGL(cg_p_update_kernel<false>, dim3(g), dim3(kT), 0, ctx->stream, n, cg->sc, cg->flags, it, cg->z, cg->x, cg->p);
     return BIS_OK;
 }

@@ -1330,3 +1330,51 @@ ORC_API double orc_host_triad(int64_t n, int reps, int *places_out, int cap) {
     free(a); free(b); free(c);
     return best;
 }
+
+/* ---- MatrixMarket writer for the ingestion figure (tools/mtx_ingest.py; test infrastructure) ----------------------------
+ * Writes a CRS matrix as `%%MatrixMarket matrix coordinate real general|symmetric`.  general: row by row, the entries of a row in
+ * CRS order (the reference's reader keeps the file's order inside a row, sparse_matrix.hpp:332-344).  symmetric: the LOWER
+ * triangle in column-major order -- the layout of the SuiteSparse files, from which the reference's reader (mirrored entry right
+ * behind its source entry, stable sort by row: :308-318) rebuilds rows with ascending columns; taken from the rows of the upper
+ * triangle, so the matrix must be symmetric in pattern and values (the caller checks).  Values with %.17g (round-trip exact).
+ * Each OpenMP thread formats a run of rows into its own buffer; the buffers are written in order.  Returns entries written. */
+ORC_API int64_t orc_write_mtx(const char *path, int64_t n, const int64_t *row_ptr, const int32_t *col, const double *val, int symmetric) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    int64_t stored = 0;
+    if (symmetric) { for (int64_t r = 0; r < n; ++r) for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) stored += col[k] >= r; }
+    else stored = row_ptr[n];
+    fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n%% written by oracle/bis_oracle.c orc_write_mtx\n%lld %lld %lld\n",
+            symmetric ? "symmetric" : "general", (long long)n, (long long)n, (long long)stored);
+    int T = 1;
+#ifdef _OPENMP
+    T = omp_get_max_threads();
+#endif
+    const int64_t pieces = (int64_t)T * 8;
+    int64_t ok = 1;
+    for (int64_t p0 = 0; p0 < pieces && ok; p0 += T) { /* T pieces at a time: bounded memory */
+        char *bufs[1024]; size_t lens[1024];
+        const int np = (int)((pieces - p0) < T ? (pieces - p0) : T);
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < np; ++t) {
+            const int64_t a = n * (p0 + t) / pieces, b = n * (p0 + t + 1) / pieces;
+            const size_t cap = (size_t)(row_ptr[b] - row_ptr[a]) * 48 + 64;
+            char *buf = (char *)malloc(cap);
+            size_t len = 0;
+            if (buf)
+                for (int64_t r = a; r < b; ++r)
+                    for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+                        if (symmetric && col[k] < r) continue;
+                        if (symmetric) len += (size_t)snprintf(buf + len, 48, "%d %lld %.17g\n", col[k] + 1, (long long)r + 1, val[k]);
+                        else len += (size_t)snprintf(buf + len, 48, "%lld %d %.17g\n", (long long)r + 1, col[k] + 1, val[k]);
+                    }
+            bufs[t] = buf; lens[t] = len;
+        }
+        for (int t = 0; t < np; ++t) {
+            if (!bufs[t] || fwrite(bufs[t], 1, lens[t], f) != lens[t]) ok = 0;
+            free(bufs[t]);
+        }
+    }
+    if (fclose(f) != 0) ok = 0;
+    return ok ? stored : -1;
+}

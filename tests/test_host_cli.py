@@ -431,3 +431,39 @@ def test_cli_mid_size_mtx_file_equals_generator_and_reference(tmp_path, oracle):
     assert os.path.exists(cache) and run(mtx, ["-cache", cache]) == gen
     e = _HM["hpcg32|sgs|none|"]
     check_history(dict(hist=np.array(from_file), iters=len(from_file) - 1, converged=True), e, "sgs", long_history=True)
+
+
+@pytest.mark.parametrize("symmetric", [0, 1])
+def test_cli_mtx_ingestion_general_and_symmetric_equals_generator(tmp_path, oracle, symmetric):
+    """The `.mtx` input path on the unstructured config-5 input (sparse_matrix.hpp:225-357: threaded parse, symmetric
+    expansion with the mirrored entry right behind its source entry, stable sort by row; utilities.hpp:326-367): unstr:20,20,20
+    (24,000 rows, 1.6e6 entries) written as a general file and as a symmetric-lower, column-major file -- the layout of the
+    SuiteSparse files config 5 names -- gives, through the CLI's binary CRS cache, the generator's CRS bit for bit, and the
+    cache reload reproduces the residual table digit for digit.  (The same at 1.04e8 entries with the timings of every phase:
+    tools/mtx_ingest.py, profiles/r05_d_mtx_ingest_unstr80.json.)"""
+    import ctypes as C
+    A = oracle.gen_unstr(20, 20, 20)
+    oracle.lib.orc_write_mtx.restype = C.c_int64
+    mtx, cache = str(tmp_path / "u.mtx"), str(tmp_path / "u.crs")
+    stored = oracle.lib.orc_write_mtx(mtx.encode(), C.c_int64(A.n_rows), A.row_ptr.ctypes, A.col.ctypes, A.val.ctypes, C.c_int(symmetric))
+    assert stored == (A.nnz if not symmetric else (A.nnz + A.n_rows) // 2)
+
+    def run():
+        out = subprocess.run([BIN, mtx, "-cg", "-p", "j", "-cache", cache], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("Matrix input:")]
+        assert len(line) == 1
+        return [float(v) for _, v in RES.findall(out.stdout)], line[0]
+
+    first, l1 = run()
+    assert ".mtx read + parse" in l1 and "COO -> CRS" in l1 and "upload" in l1
+    with open(cache, "rb") as f:
+        h = np.fromfile(f, dtype=np.int64, count=6)
+        rp = np.fromfile(f, dtype=np.int64, count=int(h[1]) + 1)
+        col = np.fromfile(f, dtype=np.int32, count=int(h[3]))
+        val = np.fromfile(f, dtype=np.float64, count=int(h[3]))
+    assert np.array_equal(rp, A.row_ptr) and np.array_equal(col, A.col) and np.array_equal(val, A.val)
+    second, l2 = run()
+    assert "binary CRS cache read" in l2 and second == first and len(first) > 10
+    gen = subprocess.run([BIN, "unstr:20,20,20", "-cg", "-p", "j"], capture_output=True, text=True, timeout=600)
+    assert [float(v) for _, v in RES.findall(gen.stdout)] == first

@@ -19,6 +19,8 @@ for rnd in range(int(os.environ.get("ROUNDS", "4"))):
         for k in ("variant", "chunk_fused", "window", "xcd_remap", "packed"):
             lib.bis_set_option(("spmv_" + k).encode(), int(c.get({"xcd_remap": "remap", "chunk_fused": "chunk"}.get(k, k), -1)))
         lib.bis_set_option(b"cg_nt_x", int(c.get("ntx", -1)))
+        lib.bis_set_option(b"spmv_valdict", int(c.get("vd", -1)))
+        lib.bis_set_option(b"spmv_win8_depth", int(c.get("w8d", -1)))
         lib.bis_set_option(b"spmv_sellwin_nt", int(c.get("ntc", -1)))
         ctx.check(lib.bis_mat_retune(ctx.h, A.h))
         ctx.init_vector(b, 1.0); ctx.init_vector(x, 0.1)
