@@ -396,6 +396,13 @@ class Mat:
         self.ctx.check(self.ctx.lib.bis_mat_debug_ptrs(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def win8_tuning(self):
+        """(re-allocations tried, kernel ms on the first allocation, kernel ms on the one kept) of the placement search the library
+        made when it built the matrix' window + sliced-ELL stream (bis_mat_win8_tuning); zeros without one."""
+        t, a, b = C.c_int(), C.c_double(), C.c_double()
+        self.ctx.lib.bis_mat_win8_tuning(self.h, C.byref(t), C.byref(a), C.byref(b))
+        return t.value, a.value, b.value
+
     def sweep_kernel(self, backward=False):
         """Name of the kernel the last forward / backward sweep on this triangle ran (bis_mat_sweep_kernel)."""
         return self.ctx.lib.bis_mat_sweep_kernel(self.h, C.c_int(int(backward))).decode()

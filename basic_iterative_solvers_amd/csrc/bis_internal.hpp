@@ -103,7 +103,8 @@ struct bis_options {
     int spmv_sellwin_joint = -1; // 0: never the 16-bit joint (slot, value) codes
     int spmv_win8 = -1;        // window + sliced-ELL SpMV with the 8-byte values streamed (matrices without a dictionary form, or with spmv_valdict = 0): 0 off, 1 on where its plan applies (-1: default = on)
     int spmv_win8_rows = -1;   // ... rows per lane: 1, 2 or 4 (blocks of 256, 512, 1024 rows; default 2)
-    int spmv_win8_depth = -1;  // ... chunks in flight per lane: 2, 3, 4 or 6 (default 4)
+    int spmv_win8_depth = -1;  // ... chunks requested ahead per lane: 1, 2, 3, 4 or 6 (default by block size)
+    int spmv_win8_tune = -1;   // ... placement tuning of the stream at build time: up to k re-allocations, the fastest kept (default 6 for streams of >= 1 GiB; 0 off)
     int spmv_sellwin_masks = -1; // 0: never the per-row pair masks (fmt 4: 4 bytes per ROW where the matrix has at most 32 (column - row, value) pairs)
     int device_share = -1;  // k > 1: this device is shared by k processes that all run persistent grids (several ranks on one GPU in a test
                             // or rehearsal): kernels that need their whole grid resident keep to 1/k of the device
@@ -330,6 +331,10 @@ int64_t bis_spmv_win8_bytes(const bis_mat *A);
 bis_status bis_spmv_win8_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y, int mode, const double *w,
                                 double *partials, const int *stop, int remap_arg, int grid);
 void bis_spmv_win8_drop(bis_mat *A);
+int bis_spmv_remap_arg(int nb);
+int bis_spmv_grid(int nb);
+size_t bis_spmv_win8_stream_bytes(const bis_mat *A);
+void *bis_spmv_win8_swap_stream(bis_mat *A, void *stream); // returns the buffer that was in use
 // try to build the packed-column stream of table t (0 plain, 1 fused); A->pk_state[t] tells the outcome
 bis_status bis_spmv_try_pack(bis_ctx *ctx, bis_mat *A, int t);
 // free row-block tables, packed streams and window structures (not the CRS arrays)

@@ -1197,6 +1197,10 @@ static bis_status ensure_packed(bis_ctx *ctx, const bis_mat *A_c, int t, SpmvArg
     return BIS_OK;
 }
 
+// the block map's kernel argument and grid for nb logical blocks (shared with the forms of bis_spmv_sell.hip)
+int bis_spmv_remap_arg(int nb) { return remap_arg_for((nb + 7) & ~7); }
+int bis_spmv_grid(int nb) { return grid_for_map(nb, remap_arg_for((nb + 7) & ~7)); }
+
 // x-window + sliced-ELL form of the dictionary kernel (bis_spmv_sell.hip) where the matrix qualifies; modes 0 and 1
 static bool sellwin_wanted(const SpmvArgs &a) {
     return a.vcode && spmv_valdict_mode() >= 2 && bis_opts().spmv_sellwin != 0 && (bis_opts().spmv_variant < 0 || bis_opts().spmv_variant == 20);

@@ -56,6 +56,8 @@ struct bis_sellwin {
     int n_pairs = 0, pair_stride = 0, diag_pair = -1; // fmt 3: pairs of the matrix, int16 words per block in blk_base, the per-row-diagonal pair
     int16_t *blk_base = nullptr;     // fmt 3: [n_blocks * pair_stride] window slot of pair e's column for the block's first row
     unsigned long long *pair_key = nullptr; // fmt 3 / 4: [256] the pairs, ascending (sw_pair_key: column - row, then value code)
+    int tune_trials = 0;             // win8: placement tuning at build time (re-allocations tried), the kernel's time on the first
+    double tune_first_ms = 0.0, tune_kept_ms = 0.0; // allocation and on the one kept
     int R = 1;                       // rows per lane: a block is 256 R rows
     bool diag = false;               // one value code stands for the row's own diagonal value (vdiag)
     int pad_idx = 0, diag_idx = 0;
@@ -1462,6 +1464,14 @@ int64_t bis_spmv_win8_bytes(const bis_mat *A) {
     return A->sw8->total_chunks * (int64_t)kW8ChunkBytes + (int64_t)A->sw8->n_blocks * 256 + 8 * (A->sw8->n_slices + 1);
 }
 
+// placement tuning (bis_mat_tune_placement): the stream's size, and an exchange of the buffer the kernel reads
+size_t bis_spmv_win8_stream_bytes(const bis_mat *A) { return A->sw8_state == 1 ? (size_t)kW8ChunkBytes * (size_t)(A->sw8->total_chunks + 1) : 0; }
+void *bis_spmv_win8_swap_stream(bis_mat *A, void *stream) {
+    void *old = A->sw8->codes;
+    A->sw8->codes = reinterpret_cast<uint32_t *>(stream);
+    return old;
+}
+
 #define W8_CHECK(call)                                                         \
     do {                                                                       \
         hipError_t e_ = (call);                                                \
@@ -1478,6 +1488,78 @@ int64_t bis_spmv_win8_bytes(const bis_mat *A) {
 
 // Build the form (A->sw8_state: 1 usable, -1 does not apply).  Rows per lane: option spmv_win8_rows (1, 2, 4), default 2 for
 // matrices of at least half a million rows.
+// Placement tuning of the stream at build time.  WHERE in HBM the stream lies decides between two levels of the kernel's time,
+// 13 % apart (HPCG-256: 0.755 / 0.855 ms; constant over time for an allocation, independent of where x and y lie, and the slow
+// level is the common one early in a process: tools/win8_place2.py, tools/win8_timeline.py, profiles/r05_f_win8_placement.log).
+// So a stream of 1 GiB or more is tried in up to k fresh allocations (option spmv_win8_tune, default 6; the earlier ones are
+// held so that the next one lands elsewhere; bounded by the free memory minus 8 GiB), each a device-to-device copy timed with
+// the kernel itself on a zero vector, and the search ends at the first allocation of the fast level.
+static bis_status w8_tune_placement(bis_ctx *ctx, bis_mat *A) {
+    bis_sellwin *sw = A->sw8;
+    const size_t bytes = bis_spmv_win8_stream_bytes(A);
+    const int k = bis_opts().spmv_win8_tune >= 0 ? bis_opts().spmv_win8_tune : (bytes >= ((size_t)1 << 30) ? 6 : 0);
+    if (k <= 0) return BIS_OK;
+    double *x = nullptr, *y = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<void *> losers;
+    auto cleanup = [&]() {
+        hipStreamSynchronize(ctx->stream);
+        for (void *l : losers) hipFree(l);
+        hipFree(x); hipFree(y);
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        (void)hipGetLastError();
+    };
+    if (hipMalloc(&x, sizeof(double) * (size_t)(A->n_cols + 2)) != hipSuccess || hipMalloc(&y, sizeof(double) * (size_t)A->n_rows) != hipSuccess ||
+        hipMemsetAsync(x, 0, sizeof(double) * (size_t)(A->n_cols + 2), ctx->stream) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return BIS_OK; } // no room to tune: keep the first allocation
+    const int nb = sw->n_blocks, remap_arg = bis_spmv_remap_arg(nb), grid = bis_spmv_grid(nb);
+    auto measure = [&](double &ms) -> bool {
+        for (int i = 0; i < 2; ++i) if (bis_spmv_win8_launch(ctx, A, x, y, 0, nullptr, nullptr, nullptr, remap_arg, grid) != BIS_OK) return false;
+        hipEventRecord(e0, ctx->stream);
+        for (int i = 0; i < 5; ++i) if (bis_spmv_win8_launch(ctx, A, x, y, 0, nullptr, nullptr, nullptr, remap_arg, grid) != BIS_OK) return false;
+        hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) return false;
+        float f = 0.f;
+        hipEventElapsedTime(&f, e0, e1);
+        ms = f / 5.0;
+        return true;
+    };
+    double best = 0.0;
+    if (!measure(best)) { cleanup(); ctx->err = "win8 placement tuning: launch failed"; return BIS_ERR_HIP; }
+    sw->tune_first_ms = best;
+    // the search ends at an allocation of the fast level: one the kernel reads at >= 5.9 TB/s (fast: 6.0-6.5, slow: 5.5 on uniform
+    // rows), or one at least 8 % faster than the slowest seen (ragged rows never reach 5.9)
+    double slowest = best;
+    auto fast_enough = [&](double ms) { return (double)bytes / (ms * 1e-3) >= 5.9e12 || ms <= 0.92 * slowest; };
+    int trials = 0;
+    for (; trials < k && !fast_enough(best); ++trials) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30)) break;
+        void *cand = nullptr;
+        if (hipMalloc(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        void *cur = bis_spmv_win8_swap_stream(A, cand);
+        hipMemcpyAsync(cand, cur, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+        double ms = 0.0;
+        if (!measure(ms)) { bis_spmv_win8_swap_stream(A, cur); losers.push_back(cand); cleanup(); ctx->err = "win8 placement tuning: launch failed"; return BIS_ERR_HIP; }
+        slowest = std::max(slowest, ms);
+        if (ms < best) { best = ms; losers.push_back(cur); }
+        else { bis_spmv_win8_swap_stream(A, cur); losers.push_back(cand); }
+    }
+    sw->tune_trials = trials;
+    sw->tune_kept_ms = best;
+    if (getenv("BIS_WIN8_STATS")) fprintf(stderr, "win8 placement: %d re-allocation(s) of %zu bytes tried, kernel %.4f ms on the first allocation, %.4f ms on the one kept\n", trials, bytes, sw->tune_first_ms, best);
+    cleanup();
+    return BIS_OK;
+}
+
+extern "C" BIS_API void bis_mat_win8_tuning(const bis_mat *A, int *trials, double *first_ms, double *kept_ms) {
+    const bool ok = A && A->sw8_state == 1;
+    if (trials) *trials = ok ? A->sw8->tune_trials : 0;
+    if (first_ms) *first_ms = ok ? A->sw8->tune_first_ms : 0.0;
+    if (kept_ms) *kept_ms = ok ? A->sw8->tune_kept_ms : 0.0;
+}
+
 bis_status bis_spmv_win8_try(bis_ctx *ctx, bis_mat *A) {
     if (A->sw8_state != 0) return BIS_OK;
     A->sw8_state = -1;
@@ -1541,8 +1623,9 @@ bis_status bis_spmv_win8_try(bis_ctx *ctx, bis_mat *A) {
     if (A->rp64) hipLaunchKernelGGL(w8_fill_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->val, A->n_rows, R, sw->hdr, sw->slice_chunk0, stream);
     else hipLaunchKernelGGL(w8_fill_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->val, A->n_rows, R, sw->hdr, sw->slice_chunk0, stream);
     W8_CHECK(hipGetLastError());
-    if (getenv("BIS_WIN8_STATS")) fprintf(stderr, "win8 plan (R = %d): %d blocks, window <= %d granules (%zu bytes), %.1f %% padding: used\n", R, nb, sw->max_gran, (size_t)(2 + 8 * sw->max_gran) * 8, 100.0 * ((double)total * 256.0 / (double)A->nnz - 1.0));
     A->sw8_state = 1;
+    if (bis_status tst = w8_tune_placement(ctx, A)) return tst;
+    if (getenv("BIS_WIN8_STATS")) fprintf(stderr, "win8 plan (R = %d): %d blocks, window <= %d granules (%zu bytes), %.1f %% padding: used; stream at %p (%zu bytes), hdr %p\n", R, nb, sw->max_gran, (size_t)(2 + 8 * sw->max_gran) * 8, 100.0 * ((double)total * 256.0 / (double)A->nnz - 1.0), (void *)sw->codes, (size_t)kW8ChunkBytes * (size_t)(total + 1), (void *)sw->hdr);
     return BIS_OK;
 }
 #undef W8_CHECK

@@ -221,6 +221,9 @@ def spmv_roofline(A, avg_s, launches, traffic_path, size):
            "moved_frac": moved / avg_s / 1e9 / HBM_PEAK_GBS,
            "streamed_bytes_per_launch": fmt["streamed_bytes_per_launch"],
            "spmv_gflops": 2.0 * nnz / avg_s / 1e9, "spmv_stream": fmt}
+    if fmt["form"] == 6:  # the library's own placement search for this stream (untimed setup, include/bis_hip.h bis_mat_win8_tuning)
+        t, first_ms, kept_ms = A.win8_tuning()
+        rec["placement_search"] = {"reallocations_tried": t, "kernel_ms_first_allocation": first_ms, "kernel_ms_kept": kept_ms}
     if not crs_stream:
         rec["crs_equivalent_GBs"] = crs_bytes / avg_s / 1e9
         rec["crs_equivalent_frac_of_peak"] = crs_bytes / avg_s / 1e9 / HBM_PEAK_GBS

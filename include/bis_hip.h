@@ -186,6 +186,12 @@ BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
  * before the first triangular solve on A (its plan caches views): refused
  * with BIS_ERR_INVALID afterwards.
  * first_ms / best_ms (optional): SpMV time before and after. */
+/* The window + sliced-ELL stream of a matrix (the SpMV's form for matrices without a value
+ * dictionary: 8-byte values + 2-byte window slots) is placement-tuned when it is built (streams
+ * of 1 GiB or more; option "spmv_win8_tune" = trials, 0 off): what the search did -- re-allocations
+ * tried, the kernel's time on the first allocation and on the one kept (ms; zeros when the matrix
+ * has no such stream or no tuning ran).  For bench / CLI records. */
+BIS_API void bis_mat_win8_tuning(const bis_mat *A, int *trials, double *first_ms, double *kept_ms);
 BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_trials,
                                           double *first_ms, double *best_ms);
 /* device addresses of the CRS arrays (tuning / zero-copy interop).  A caller that
