@@ -32,6 +32,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -1550,6 +1551,18 @@ static bis_status w8_tune_placement(bis_ctx *ctx, bis_mat *A) {
     sw->tune_kept_ms = best;
     if (getenv("BIS_WIN8_STATS")) fprintf(stderr, "win8 placement: %d re-allocation(s) of %zu bytes tried, kernel %.4f ms on the first allocation, %.4f ms on the one kept\n", trials, bytes, sw->tune_first_ms, best);
     cleanup();
+    return BIS_OK;
+}
+
+// debugging / tuning aid (tools/win8_offsets.py): the stream's address and size; *set != NULL: read the stream from there from now
+// on (the caller owns that memory and has copied the stream into it; the library's own buffer stays allocated)
+extern "C" BIS_API bis_status bis_mat_win8_debug_stream(bis_mat *A, void **ptr, size_t *bytes, void *set) {
+    if (!A || A->sw8_state != 1) return BIS_ERR_INVALID;
+    static std::map<bis_mat *, void *> own; // the library's buffer of a matrix whose stream was redirected
+    if (ptr) *ptr = own.count(A) ? own[A] : (void *)A->sw8->codes;
+    if (bytes) *bytes = bis_spmv_win8_stream_bytes(A);
+    if (set) { if (!own.count(A)) own[A] = (void *)A->sw8->codes; A->sw8->codes = reinterpret_cast<uint32_t *>(set); }
+    else if (own.count(A)) { A->sw8->codes = reinterpret_cast<uint32_t *>(own[A]); own.erase(A); }
     return BIS_OK;
 }
 

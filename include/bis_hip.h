@@ -192,6 +192,10 @@ BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
  * tried, the kernel's time on the first allocation and on the one kept (ms; zeros when the matrix
  * has no such stream or no tuning ran).  For bench / CLI records. */
 BIS_API void bis_mat_win8_tuning(const bis_mat *A, int *trials, double *first_ms, double *kept_ms);
+/* debugging / tuning aid (tools/win8_offsets.py): address and size of that stream; set != NULL: the
+ * kernel reads the stream from `set` from now on (memory of the caller, into which it has copied the
+ * stream), set == NULL: back to the library's own buffer. */
+BIS_API bis_status bis_mat_win8_debug_stream(bis_mat *A, void **ptr, size_t *bytes, void *set);
 BIS_API bis_status bis_mat_tune_placement(bis_ctx *ctx, bis_mat *A, int max_trials,
                                           double *first_ms, double *best_ms);
 /* device addresses of the CRS arrays (tuning / zero-copy interop).  A caller that
