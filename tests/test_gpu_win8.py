@@ -147,3 +147,36 @@ def test_win8_in_fused_cg(ctx, oracle, rows):
     finally:
         for k in ("spmv_valdict", "spmv_win8_rows", "spmv_win8"):
             ctx.set_option(k, -1)
+
+
+def test_win8_placement_search_and_its_record(ctx, oracle):
+    """A stream of >= 1 GiB is placement-searched when it is built (bis_spmv_sell.hip w8_tune_placement): the search keeps an
+    allocation at least as fast as the first one, reports what it did (bis_mat_win8_tuning), can be switched off, and whichever
+    allocation it keeps holds the same stream: y is bit-identical.  (HPCG-160: 4.1 M rows, 1.14 GiB of stream.)"""
+    n1 = 160
+    N = n1 ** 3
+    x = ctx.upload(np.random.default_rng(8).uniform(-1, 1, N))
+    ys = {}
+    ctx.set_option("spmv_valdict", 0)
+    try:
+        for tune in (0, 4, -1):
+            ctx.set_option("spmv_win8_tune", tune)
+            dA = ctx.gen_hpcg(n1)
+            y = ctx.alloc(N)
+            ctx.spmv(dA, x, y)
+            assert dA.spmv_stream_info()[3] == 6
+            trials, first_ms, kept_ms = dA.win8_tuning()
+            if tune == 0:
+                assert (trials, first_ms, kept_ms) == (0, 0.0, 0.0)
+            else:
+                assert 0 <= trials <= (4 if tune == 4 else 6) and first_ms > 0 and 0 < kept_ms <= first_ms
+            ys[tune] = y.to_host()
+            dA.free(); y.free()
+        assert np.array_equal(ys[0], ys[4]) and np.array_equal(ys[0], ys[-1])
+        A = oracle.gen_hpcg(n1, row0=1000000, row1=1050000)
+        yo = oracle.spmv(A, x.to_host())
+        assert np.max(np.abs(ys[-1][1000000:1050000] - yo)) <= KTOL * np.max(np.abs(yo))
+    finally:
+        ctx.set_option("spmv_valdict", -1)
+        ctx.set_option("spmv_win8_tune", -1)
+    x.free()
