@@ -32,7 +32,6 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
-#include <map>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -57,6 +56,7 @@ struct bis_sellwin {
     int n_pairs = 0, pair_stride = 0, diag_pair = -1; // fmt 3: pairs of the matrix, int16 words per block in blk_base, the per-row-diagonal pair
     int16_t *blk_base = nullptr;     // fmt 3: [n_blocks * pair_stride] window slot of pair e's column for the block's first row
     unsigned long long *pair_key = nullptr; // fmt 3 / 4: [256] the pairs, ascending (sw_pair_key: column - row, then value code)
+    void *own_codes = nullptr;       // win8: the library's own stream while a debugging caller has redirected `codes` (bis_mat_win8_debug_stream)
     int tune_trials = 0;             // win8: placement tuning at build time (re-allocations tried), the kernel's time on the first
     double tune_first_ms = 0.0, tune_kept_ms = 0.0; // allocation and on the one kept
     int R = 1;                       // rows per lane: a block is 256 R rows
@@ -1449,6 +1449,7 @@ __global__ __launch_bounds__(256) void spmv_win8_kernel(
 
 void bis_spmv_win8_drop(bis_mat *A) {
     if (A->sw8) {
+        if (A->sw8->own_codes) A->sw8->codes = reinterpret_cast<uint32_t *>(A->sw8->own_codes); // (a redirected stream is the caller's memory: never freed here)
         hipFree(A->sw8->hdr); hipFree(A->sw8->slice_chunk0); hipFree(A->sw8->own_rank); hipFree(A->sw8->codes);
         delete A->sw8;
         A->sw8 = nullptr;
@@ -1558,11 +1559,11 @@ static bis_status w8_tune_placement(bis_ctx *ctx, bis_mat *A) {
 // on (the caller owns that memory and has copied the stream into it; the library's own buffer stays allocated)
 extern "C" BIS_API bis_status bis_mat_win8_debug_stream(bis_mat *A, void **ptr, size_t *bytes, void *set) {
     if (!A || A->sw8_state != 1) return BIS_ERR_INVALID;
-    static std::map<bis_mat *, void *> own; // the library's buffer of a matrix whose stream was redirected
-    if (ptr) *ptr = own.count(A) ? own[A] : (void *)A->sw8->codes;
+    bis_sellwin *sw = A->sw8;
+    if (ptr) *ptr = sw->own_codes ? sw->own_codes : (void *)sw->codes;
     if (bytes) *bytes = bis_spmv_win8_stream_bytes(A);
-    if (set) { if (!own.count(A)) own[A] = (void *)A->sw8->codes; A->sw8->codes = reinterpret_cast<uint32_t *>(set); }
-    else if (own.count(A)) { A->sw8->codes = reinterpret_cast<uint32_t *>(own[A]); own.erase(A); }
+    if (set) { if (!sw->own_codes) sw->own_codes = (void *)sw->codes; sw->codes = reinterpret_cast<uint32_t *>(set); }
+    else if (sw->own_codes) { sw->codes = reinterpret_cast<uint32_t *>(sw->own_codes); sw->own_codes = nullptr; }
     return BIS_OK;
 }
 

@@ -20,7 +20,7 @@ Three pieces, all plain files and threads (no GPU, no torch):
   the exit status is non-zero.  A restart, if anyone wants one, is a fresh child: nothing here re-executes a process that
   has touched the GPU.
 
-Environment: BIS_PHASE_DIR (the board; made by `supervise`, else /tmp/bis_phases_<MASTER_PORT>), BIS_PHASE_LIMIT_S (one
+Environment: BIS_PHASE_DIR (the board; made by `supervise`, else /tmp/bis_phases_<MASTER_PORT>_<launcher pid>), BIS_PHASE_LIMIT_S (one
 limit for every phase: tests), BIS_BENCH_STUCK="rank:phase:seconds" (test hook: that rank sleeps when it enters the phase).
 """
 import json
@@ -50,7 +50,9 @@ def limit_of(phase):
 def board_dir():
     d = os.environ.get("BIS_PHASE_DIR")
     if not d:
-        d = os.path.join("/tmp", "bis_phases_%s" % os.environ.get("MASTER_PORT", str(os.getppid())))
+        # the ranks of one launch are children of one launcher process: its pid (and the rendezvous port) name a board that no
+        # earlier launch has written to
+        d = os.path.join("/tmp", "bis_phases_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
     os.makedirs(d, exist_ok=True)
     return d
 
@@ -67,8 +69,11 @@ def read_board(d, world=None):
         if not f.startswith("rank_"):
             continue
         try:
+            rank = int(f[5:])
+            if world and rank >= world:
+                continue  # (a file an earlier, larger run left on a board that is found by the rendezvous port)
             phase, seq, t, label = (open(os.path.join(d, f)).read().split(None, 3) + [""])[:4]
-            out[int(f[5:])] = (phase, now - float(t), int(seq), label.strip())
+            out[rank] = (phase, now - float(t), int(seq), label.strip())
         except Exception:
             pass
     if world:
