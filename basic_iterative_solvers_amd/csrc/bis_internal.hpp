@@ -104,7 +104,7 @@ struct bis_options {
     int spmv_win8 = -1;        // window + sliced-ELL SpMV with the 8-byte values streamed (matrices without a dictionary form, or with spmv_valdict = 0): 0 off, 1 on where its plan applies (-1: default = on)
     int spmv_win8_rows = -1;   // ... rows per lane: 1, 2 or 4 (blocks of 256, 512, 1024 rows; default 2)
     int spmv_win8_depth = -1;  // ... chunks requested ahead per lane: 1, 2, 3, 4 or 6 (default by block size)
-    int spmv_win8_tune = -1;   // ... placement tuning of the stream at build time: up to k re-allocations, the fastest kept (default 6 for streams of >= 1 GiB; 0 off)
+    int spmv_win8_tune = -1;   // ... placement tuning of the stream at build time: up to k re-allocations, the fastest kept (default 12 for streams of >= 1 GiB; 0 off)
     int spmv_sellwin_masks = -1; // 0: never the per-row pair masks (fmt 4: 4 bytes per ROW where the matrix has at most 32 (column - row, value) pairs)
     int device_share = -1;  // k > 1: this device is shared by k processes that all run persistent grids (several ranks on one GPU in a test
                             // or rehearsal): kernels that need their whole grid resident keep to 1/k of the device

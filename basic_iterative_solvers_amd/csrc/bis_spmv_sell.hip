@@ -56,6 +56,7 @@ struct bis_sellwin {
     int n_pairs = 0, pair_stride = 0, diag_pair = -1; // fmt 3: pairs of the matrix, int16 words per block in blk_base, the per-row-diagonal pair
     int16_t *blk_base = nullptr;     // fmt 3: [n_blocks * pair_stride] window slot of pair e's column for the block's first row
     unsigned long long *pair_key = nullptr; // fmt 3 / 4: [256] the pairs, ascending (sw_pair_key: column - row, then value code)
+    uint16_t *row_of = nullptr;      // win8: [n_blocks * 256 R] row (in its block) of every position of the block's length order
     void *own_codes = nullptr;       // win8: the library's own stream while a debugging caller has redirected `codes` (bis_mat_win8_debug_stream)
     int tune_trials = 0;             // win8: placement tuning at build time (re-allocations tried), the kernel's time on the first
     double tune_first_ms = 0.0, tune_kept_ms = 0.0; // allocation and on the one kept
@@ -1246,22 +1247,176 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
 // Entry j of a row is entry j of the CRS row; product and sum are rounded separately, in CRS order: y is bit-identical to
 // the other kernels'.  Padding: value 1.0 at the slot that holds -0.0.  The CRS arrays stay authoritative (the stream is a
 // lossless re-layout of val, built on the device at the first SpMV and dropped when values change).
-// Usable by any matrix whose blocks of 256 R rows read a few contiguous runs of x (banded / stencil / RCM-ordered meshes)
-// and whose rows within a 64-row slice have similar lengths (<= 30 % padding).
+// Usable by any matrix whose blocks of 256 R rows read at most 64 runs / 60 KB of x (runs a few granules apart are merged: banded /
+// stencil orderings, RCM-ordered meshes); the rows of a block are taken in order of their length (w8_plan_kernel), so rows of
+// very different lengths do not pad each other (still refused beyond 30 % padding).
 namespace {
 
 constexpr int kW8ChunkBytes = 2560;
 
+
+constexpr int kW8Runs = 64;     // runs of the window per block at most (header: 2 x 64 words)
+constexpr int kW8GapMerge = 4;  // runs at most this many granules apart become one (the gap's x entries are copied too)
+
+// win8's own plan, one workgroup per block of 256 R rows:
+//  * the 8-column granules of x the block reads (LDS hash set, bitonic sort), cut into runs of consecutive granules; runs at most
+//    kW8GapMerge granules apart are MERGED (an RCM-ordered mesh reads many short runs with small gaps: 34 raw runs per 1024-row
+//    block become 23), runs of more than 64 granules split (a wave copies 64 x 64 bytes per instruction); at most kW8Runs runs
+//    and max_gran granules (gaps included), else status[0] = 1;
+//  * the block's rows SORTED BY LENGTH, longest first (stable: equal lengths keep their order), 64 sorted positions = one slice:
+//    a slice is padded to ITS longest row, so rows of very different lengths no longer pad each other (FEM-like rows of 18-81
+//    entries: 19 % padding -> 4 %).  row_of[b * 256 R + position] = row in the block; own_rank[b] >= 0 only where the order is
+//    the identity (every row as long as the first, or already descending) and the own columns lie in the window side by side.
+template <typename RP>
+__global__ __launch_bounds__(256) void w8_plan_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col, int64_t n_rows, int R,
+                                                      int max_gran, int64_t row0, int32_t *__restrict__ hdr, int32_t *__restrict__ slice_chunks,
+                                                      int32_t *__restrict__ own_rank, uint16_t *__restrict__ row_of, int *status) {
+    __shared__ int table[kSwHash];
+    __shared__ int list[1024];
+    __shared__ int keys[1024]; // (length << 10 | 1023 - row) of the block's rows: descending order = longest first, equal lengths by row
+    __shared__ int cnt, failed, n_out, win_gran, own_s, ident;
+    __shared__ int out_g0[kW8Runs], out_rk[kW8Runs];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t r0 = (int64_t)b * kSwRows * R;
+    const int rows = (int)min((int64_t)kSwRows * R, n_rows - r0);
+    const int cap = kSwRows * R; // 256, 512 or 1024
+    for (int i = tid; i < kSwHash; i += 256) table[i] = -1;
+    if (tid == 0) { cnt = 0; failed = 0; n_out = 0; win_gran = 0; own_s = -1; ident = 1; }
+    __syncthreads();
+    // rows by length
+    for (int i = tid; i < 1024; i += 256) {
+        int len = -1; // (positions past the block's rows sort behind every row)
+        if (i < rows) len = (int)((int64_t)row_ptr[r0 + i + 1] - (int64_t)row_ptr[r0 + i]);
+        keys[i] = i < cap ? ((min(len, (1 << 20) - 1) + 1) << 10 | (1023 - i)) : -1;
+    }
+    __syncthreads();
+    for (int k = 2; k <= 1024; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < 1024; i += 256) {
+                const int o = i ^ j;
+                if (o > i) {
+                    const int a = keys[i], c = keys[o];
+                    if ((a < c) == ((i & k) == 0)) { keys[i] = c; keys[o] = a; } // descending
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < cap; i += 256) {
+        const int row = 1023 - (keys[i] & 1023);
+        row_of[(size_t)b * cap + i] = (uint16_t)row;
+        if (row != i) atomicExch(&ident, 0);
+        if ((i & 63) == 0) { // first (= longest) row of slice i / 64
+            const int len = (keys[i] >> 10) - 1;
+            const int ch = len > 0 ? (len + 3) >> 2 : 0;
+            slice_chunks[(size_t)b * 4 * R + (i >> 6)] = ch;
+            atomicMax(&status[5], ch);
+        }
+    }
+    // granules
+    const int64_t s = (int64_t)row_ptr[r0], e = (int64_t)row_ptr[r0 + rows];
+    for (int64_t k = s + tid; k < e; k += 256) {
+        if (__hip_atomic_load(&failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        const int g = col[k] >> 3;
+        unsigned h = ((unsigned)g * 2654435761u) >> 20;
+        for (;;) {
+            const int cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (cur == g) break;
+            if (cur == -1) {
+                const int old = atomicCAS(&table[h], -1, g);
+                if (old == -1) {
+                    if (atomicAdd(&cnt, 1) >= max_gran) atomicExch(&failed, 1);
+                    break;
+                }
+                if (old == g) break;
+            }
+            h = (h + 1) & (kSwHash - 1);
+        }
+    }
+    __syncthreads();
+    const int n = cnt;
+    if (failed || n > max_gran) {
+        if (tid == 0) atomicExch(&status[0], 1);
+        return;
+    }
+    __syncthreads();
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < kSwHash; i += 256) {
+        const int g = table[i];
+        if (g != -1) list[atomicAdd(&cnt, 1)] = g;
+    }
+    int P = 2;
+    while (P < n) P <<= 1;
+    __syncthreads();
+    for (int i = n + tid; i < P; i += 256) list[i] = INT32_MAX;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 256) {
+                const int o = i ^ j;
+                if (o > i) {
+                    const int a = list[i], c = list[o];
+                    if ((a > c) == ((i & k) == 0)) { list[i] = c; list[o] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) { // one thread walks the sorted granules: merge, split, rank (a setup kernel: ~n steps)
+        int m = 0, rank = 0; // runs emitted, granules of the window so far (gaps included)
+        int i = 0;
+        bool ok = true;
+        const int64_t c_first = r0 + row0, c_last = c_first + rows - 1;
+        const int g_first = (int)(c_first >> 3), g_last = (int)(c_last >> 3);
+        int own = -1;
+        while (i < n && ok) {
+            const int g0 = list[i];
+            int g1 = g0; // last granule of the merged run
+            ++i;
+            while (i < n && list[i] - g1 <= kW8GapMerge + 1) { g1 = list[i]; ++i; }
+            const int len = g1 - g0 + 1;
+            if ((c_first & 7) == 0 && g0 <= g_first && g_last <= g1) own = rank + (g_first - g0);
+            for (int o = 0; o < len && ok; o += kSwRunGran) {
+                if (m >= kW8Runs) { ok = false; break; }
+                out_g0[m] = g0 + o;
+                out_rk[m] = (rank + o) | (min(kSwRunGran, len - o) << 16);
+                ++m;
+            }
+            rank += len;
+            if (rank > max_gran) ok = false;
+        }
+        if (!ok) atomicExch(&failed, 1);
+        n_out = m;
+        win_gran = rank;
+        own_s = own;
+    }
+    __syncthreads();
+    if (failed) {
+        if (tid == 0) atomicExch(&status[0], 1);
+        return;
+    }
+    if (tid < 2 * kW8Runs) {
+        const int k = tid % kW8Runs;
+        int word = 0;
+        if (k < n_out) word = tid < kW8Runs ? out_g0[k] : out_rk[k];
+        hdr[(size_t)b * 2 * kW8Runs + tid] = word;
+    }
+    if (tid == 0) {
+        own_rank[b] = ident ? own_s : -1;
+        atomicMax(&status[1], win_gran);
+    }
+}
+
 template <typename RP>
 __global__ __launch_bounds__(256) void w8_fill_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col, const double *__restrict__ val,
                                                       int64_t n_rows, int R, const int32_t *__restrict__ hdr,
-                                                      const int64_t *__restrict__ slice_chunk0, unsigned char *__restrict__ stream) {
-    __shared__ int g0s[kSwRuns], rk[kSwRuns];
+                                                      const int64_t *__restrict__ slice_chunk0, const uint16_t *__restrict__ row_of,
+                                                      unsigned char *__restrict__ stream) {
+    __shared__ int g0s[kW8Runs], rk[kW8Runs];
     __shared__ int nr_s;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < kSwRuns) {
-        g0s[tid] = hdr[(size_t)b * 64 + tid];
-        const int w2 = hdr[(size_t)b * 64 + 32 + tid];
+    if (tid < kW8Runs) {
+        g0s[tid] = hdr[(size_t)b * 2 * kW8Runs + tid];
+        const int w2 = hdr[(size_t)b * 2 * kW8Runs + kW8Runs + tid];
         rk[tid] = w2 & 0xffff;
         const unsigned long long m = __ballot((w2 >> 16) != 0);
         if (tid == 0) nr_s = __popcll(m);
@@ -1270,7 +1425,8 @@ __global__ __launch_bounds__(256) void w8_fill_kernel(const RP *__restrict__ row
     const int nr = nr_s;
     for (int rr = 0; rr < R; ++rr) {
         const int64_t slice = ((int64_t)b * 4 + wv) * R + rr;
-        const int64_t r = slice * 64 + lane;
+        const int64_t pos = slice * 64 + lane; // position in the block's length order
+        const int64_t r = (int64_t)b * kSwRows * R + row_of[pos];
         int64_t rs = 0;
         int len = 0;
         if (r < n_rows) {
@@ -1344,7 +1500,7 @@ template <int MODE, int R, int D>
 __global__ __launch_bounds__(256) void spmv_win8_kernel(
     const double *x, double *__restrict__ y, int64_t n_rows, int64_t n_cols, int n_blocks, int remap_arg, const double *w,
     double *__restrict__ partials, const int *stop, const int32_t *__restrict__ hdr, const int64_t *__restrict__ slice_chunk0,
-    const unsigned char *__restrict__ stream, int x_al16, const int32_t *__restrict__ own_rank) {
+    const unsigned char *__restrict__ stream, int x_al16, const int32_t *__restrict__ own_rank, const uint16_t *__restrict__ row_of) {
     if (stop && stop[1]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int b = remap_arg > 0 ? xcd_remap(blockIdx.x, remap_arg)
@@ -1352,8 +1508,12 @@ __global__ __launch_bounds__(256) void spmv_win8_kernel(
     if (b >= n_blocks) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hw = hdr[(size_t)b * 64 + lane];
+    const int hw_g = hdr[(size_t)b * 2 * kW8Runs + lane], hw_r = hdr[(size_t)b * 2 * kW8Runs + kW8Runs + lane]; // run k: first granule / rank | granules << 16
     const int64_t slice0 = ((int64_t)b * 4 + wv) * R;
+    const int64_t block_row0 = (int64_t)b * kSwRows * R;
+    int64_t rows_of[R]; // the rows this lane owns: position (slice, lane) of the block's length order -> row
+#pragma unroll
+    for (int r = 0; r < R; ++r) rows_of[r] = block_row0 + row_of[(slice0 + r) * 64 + lane];
     // chunk boundaries of the wave's slices: lane r holds slice_chunk0[slice0 + r], r <= R
     const int64_t my_bnd = slice_chunk0[slice0 + min(lane, R)];
     auto bnd = [&](int r) {
@@ -1373,16 +1533,16 @@ __global__ __launch_bounds__(256) void spmv_win8_kernel(
     if (MODE == 1 && own_rank) own = own_rank[b];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t row = (slice0 + r) * 64 + lane;
+        const int64_t row = rows_of[r];
         wr[r] = (MODE == 1 && own < 0 && row < n_rows) ? w[row] : 0.0;
     }
     if (tid == 0) *reinterpret_cast<double *>(lds) = -0.0;
     {   // window: the runs of 8-column granules, 16-byte pieces by LDS-DMA (as spmv_sellwin_kernel)
-        const int n_runs = __popcll(__ballot(lane >= 32 && (hw >> 16) != 0));
+        const int n_runs = __popcll(__ballot((hw_r >> 16) != 0));
         unsigned char *win = lds + 16;
         for (int k = 0; k < n_runs; ++k) {
-            const int g0 = __builtin_amdgcn_readlane(hw, k);
-            const int w2 = __builtin_amdgcn_readlane(hw, 32 + k);
+            const int g0 = __builtin_amdgcn_readlane(hw_g, k);
+            const int w2 = __builtin_amdgcn_readlane(hw_r, k);
             const int rank = w2 & 0xffff, n_pieces = (w2 >> 16) * 4;
             const int j = (wv + k) & 3;
             const int p = j * 64 + lane;
@@ -1419,7 +1579,7 @@ __global__ __launch_bounds__(256) void spmv_win8_kernel(
 #define W8_END_SLICES()                                                                    \
     _Pragma("unroll") for (int rr = 0; rr < R; ++rr)                                       \
         if (rr == next && c == e[rr]) {                                                    \
-            const int64_t row = (slice0 + rr) * 64 + lane;                                 \
+            const int64_t row = rows_of[rr];                                               \
             if (row < n_rows) y[row] = acc;                                                \
             if (MODE == 1) dot_acc += row < n_rows ? acc * wr[rr] : 0.0;                   \
             acc = 0.0;                                                                     \
@@ -1450,7 +1610,7 @@ __global__ __launch_bounds__(256) void spmv_win8_kernel(
 void bis_spmv_win8_drop(bis_mat *A) {
     if (A->sw8) {
         if (A->sw8->own_codes) A->sw8->codes = reinterpret_cast<uint32_t *>(A->sw8->own_codes); // (a redirected stream is the caller's memory: never freed here)
-        hipFree(A->sw8->hdr); hipFree(A->sw8->slice_chunk0); hipFree(A->sw8->own_rank); hipFree(A->sw8->codes);
+        hipFree(A->sw8->hdr); hipFree(A->sw8->slice_chunk0); hipFree(A->sw8->own_rank); hipFree(A->sw8->codes); hipFree(A->sw8->row_of);
         delete A->sw8;
         A->sw8 = nullptr;
     }
@@ -1463,7 +1623,7 @@ int64_t bis_spmv_win8_partials(const bis_mat *A) { return A->sw8_state == 1 ? (i
 // bytes of the form's own arrays one launch reads: the stream (with its padding), block headers, slice offsets
 int64_t bis_spmv_win8_bytes(const bis_mat *A) {
     if (A->sw8_state != 1) return 0;
-    return A->sw8->total_chunks * (int64_t)kW8ChunkBytes + (int64_t)A->sw8->n_blocks * 256 + 8 * (A->sw8->n_slices + 1);
+    return A->sw8->total_chunks * (int64_t)kW8ChunkBytes + (int64_t)A->sw8->n_blocks * (8 * kW8Runs + 2 * kSwRows * A->sw8->R) + 8 * (A->sw8->n_slices + 1);
 }
 
 // placement tuning (bis_mat_tune_placement): the stream's size, and an exchange of the buffer the kernel reads
@@ -1493,13 +1653,14 @@ void *bis_spmv_win8_swap_stream(bis_mat *A, void *stream) {
 // Placement tuning of the stream at build time.  WHERE in HBM the stream lies decides between two levels of the kernel's time,
 // 13 % apart (HPCG-256: 0.755 / 0.855 ms; constant over time for an allocation, independent of where x and y lie, and the slow
 // level is the common one early in a process: tools/win8_place2.py, tools/win8_timeline.py, profiles/r05_f_win8_placement.log).
-// So a stream of 1 GiB or more is tried in up to k fresh allocations (option spmv_win8_tune, default 6; the earlier ones are
+// So a stream of 1 GiB or more is tried in up to k fresh allocations (option spmv_win8_tune, default 12 -- five slow allocations
+// in a row have been seen --; the earlier ones are
 // held so that the next one lands elsewhere; bounded by the free memory minus 8 GiB), each a device-to-device copy timed with
 // the kernel itself on a zero vector, and the search ends at the first allocation of the fast level.
 static bis_status w8_tune_placement(bis_ctx *ctx, bis_mat *A) {
     bis_sellwin *sw = A->sw8;
     const size_t bytes = bis_spmv_win8_stream_bytes(A);
-    const int k = bis_opts().spmv_win8_tune >= 0 ? bis_opts().spmv_win8_tune : (bytes >= ((size_t)1 << 30) ? 6 : 0);
+    const int k = bis_opts().spmv_win8_tune >= 0 ? bis_opts().spmv_win8_tune : (bytes >= ((size_t)1 << 30) ? 12 : 0);
     if (k <= 0) return BIS_OK;
     double *x = nullptr, *y = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1574,15 +1735,29 @@ extern "C" BIS_API void bis_mat_win8_tuning(const bis_mat *A, int *trials, doubl
     if (kept_ms) *kept_ms = ok ? A->sw8->tune_kept_ms : 0.0;
 }
 
+static bis_status w8_try_rows(bis_ctx *ctx, bis_mat *A, int R, bool *window_too_large);
+
 bis_status bis_spmv_win8_try(bis_ctx *ctx, bis_mat *A) {
     if (A->sw8_state != 0) return BIS_OK;
     A->sw8_state = -1;
     if (A->n_rows == 0 || A->nnz == 0 || A->n_cols >= ((int64_t)1 << 31) - 16) return BIS_OK;
     // default 4 rows per lane (blocks of 1024 rows): HPCG-256 0.78 ms against 0.86 with 2 and 1.20 with 1 -- the larger the block, the
-    // fewer times an x entry is copied into some block's window (tools/win8_probe.py, profiles/r05_c_win8_probe.log)
+    // fewer times an x entry is copied into some block's window (tools/win8_probe.py, profiles/r05_c_win8_probe.log).  Where a
+    // block of that size reads more than 64 runs / 60 KB of x the plan is made again with half the rows (an RCM-ordered mesh of
+    // 1.5 M rows: not representable with 1024 rows, 43.6 KB windows with 512: 0.193 against 0.237 ms for the row-block kernel).
     int R = bis_opts().spmv_win8_rows > 0 ? std::min(bis_opts().spmv_win8_rows, 4) : 4;
     if (R == 3) R = 2;
     while (R > 1 && A->n_rows < (int64_t)kSwRows * R * 1024) R >>= 1;
+    for (;; R >>= 1) {
+        bool too_large = false;
+        if (bis_status st = w8_try_rows(ctx, A, R, &too_large)) return st;
+        if (A->sw8_state == 1 || !too_large || R == 1 || bis_opts().spmv_win8_rows > 0) return BIS_OK;
+        A->sw8_state = -1;
+    }
+}
+
+static bis_status w8_try_rows(bis_ctx *ctx, bis_mat *A, int R, bool *window_too_large) {
+    *window_too_large = false;
     const int64_t nb64 = (A->n_rows + (int64_t)kSwRows * R - 1) / ((int64_t)kSwRows * R);
     if (nb64 > (int64_t)1 << 26) return BIS_OK;
     const int nb = (int)nb64;
@@ -1595,17 +1770,18 @@ bis_status bis_spmv_win8_try(bis_ctx *ctx, bis_mat *A) {
     int32_t *slice_chunks = nullptr;
     void *tmp = nullptr;
     int *status = (int *)ctx->counters + 52;
-    W8_CHECK(hipMalloc(&sw->hdr, sizeof(int32_t) * 64 * (size_t)nb));
+    W8_CHECK(hipMalloc(&sw->hdr, sizeof(int32_t) * 2 * kW8Runs * (size_t)nb));
     W8_CHECK(hipMalloc(&sw->own_rank, sizeof(int32_t) * (size_t)nb));
     W8_CHECK(hipMemsetAsync(sw->own_rank, 0xFF, sizeof(int32_t) * (size_t)nb, ctx->stream)); // (blocks the plan leaves early: -1)
+    W8_CHECK(hipMalloc(&sw->row_of, sizeof(uint16_t) * (size_t)nb * kSwRows * (size_t)R));
     W8_CHECK(hipMalloc(&slice_chunks, sizeof(int32_t) * (size_t)(sw->n_slices + 1)));
     W8_CHECK(hipMalloc(&sw->slice_chunk0, sizeof(int64_t) * (size_t)(sw->n_slices + 1)));
     W8_CHECK(hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream));
     W8_CHECK(hipMemsetAsync(status + 5, 0, sizeof(int), ctx->stream));
     W8_CHECK(hipMemsetAsync(slice_chunks, 0, sizeof(int32_t) * (size_t)(sw->n_slices + 1), ctx->stream));
-    W8_CHECK(hipMemsetAsync(sw->hdr, 0, sizeof(int32_t) * 64 * (size_t)nb, ctx->stream));
-    if (A->rp64) hipLaunchKernelGGL(sw_plan_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->n_rows, R, kSwMaxGran, A->view_row0, sw->hdr, slice_chunks, sw->own_rank, status);
-    else hipLaunchKernelGGL(sw_plan_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->n_rows, R, kSwMaxGran, A->view_row0, sw->hdr, slice_chunks, sw->own_rank, status);
+    W8_CHECK(hipMemsetAsync(sw->hdr, 0, sizeof(int32_t) * 2 * kW8Runs * (size_t)nb, ctx->stream));
+    if (A->rp64) hipLaunchKernelGGL(w8_plan_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->n_rows, R, kSwMaxGran, A->view_row0, sw->hdr, slice_chunks, sw->own_rank, sw->row_of, status);
+    else hipLaunchKernelGGL(w8_plan_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->n_rows, R, kSwMaxGran, A->view_row0, sw->hdr, slice_chunks, sw->own_rank, sw->row_of, status);
     W8_CHECK(hipGetLastError());
     int h[2] = {0, 0};
     W8_CHECK(hipMemcpyAsync(h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -1623,9 +1799,11 @@ bis_status bis_spmv_win8_try(bis_ctx *ctx, bis_mat *A) {
     hipFree(slice_chunks); slice_chunks = nullptr;
     sw->total_chunks = total;
     sw->max_gran = h[1];
-    // not representable (more than 32 runs / 60 KiB of window in some block), or more than 30 % of padding: the gather kernel stays
-    if (h[0] || (double)total * 256.0 > 1.3 * (double)A->nnz + 256.0 * 4 * 64) {
+    // not representable (more than 64 runs / 60 KiB of window in some block), or more than 12 % of padding (every padded entry costs
+    // 10 streamed bytes: Anderson's 7-entry rows in 8 slots, 14 %, run 0.310 ms against 0.297 for the row-block kernel): that kernel stays
+    if (h[0] || (double)total * 256.0 > 1.12 * (double)A->nnz + 256.0 * 4 * 64) {
         if (getenv("BIS_WIN8_STATS")) fprintf(stderr, "win8 plan (R = %d): %s, %.1f %% padding: not used\n", R, h[0] ? "window not representable" : "representable", 100.0 * ((double)total * 256.0 / (double)A->nnz - 1.0));
+        *window_too_large = h[0] != 0;
         bis_spmv_win8_drop(A);
         A->sw8_state = -1;
         return BIS_OK;
@@ -1634,8 +1812,8 @@ bis_status bis_spmv_win8_try(bis_ctx *ctx, bis_mat *A) {
     W8_CHECK(hipMalloc(&stream, (size_t)kW8ChunkBytes * (size_t)(total + 1)));
     sw->codes = reinterpret_cast<uint32_t *>(stream);
     W8_CHECK(hipMemsetAsync(stream + (size_t)total * kW8ChunkBytes, 0, kW8ChunkBytes, ctx->stream));
-    if (A->rp64) hipLaunchKernelGGL(w8_fill_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->val, A->n_rows, R, sw->hdr, sw->slice_chunk0, stream);
-    else hipLaunchKernelGGL(w8_fill_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->val, A->n_rows, R, sw->hdr, sw->slice_chunk0, stream);
+    if (A->rp64) hipLaunchKernelGGL(w8_fill_kernel<int64_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int64_t *)A->row_ptr, A->col, A->val, A->n_rows, R, sw->hdr, sw->slice_chunk0, sw->row_of, stream);
+    else hipLaunchKernelGGL(w8_fill_kernel<int32_t>, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t *)A->row_ptr, A->col, A->val, A->n_rows, R, sw->hdr, sw->slice_chunk0, sw->row_of, stream);
     W8_CHECK(hipGetLastError());
     A->sw8_state = 1;
     if (bis_status tst = w8_tune_placement(ctx, A)) return tst;
@@ -1657,7 +1835,7 @@ bis_status bis_spmv_win8_launch(bis_ctx *ctx, const bis_mat *A, const double *x,
     const bool ragged = (double)sw->total_chunks * 256.0 > 1.08 * (double)A->nnz;
     const int depth = bis_opts().spmv_win8_depth > 0 ? bis_opts().spmv_win8_depth : (sw->R == 4 ? (ragged ? 2 : 1) : 3);
 #define W8_L3(MODE, RR, DD) hipLaunchKernelGGL((spmv_win8_kernel<MODE, RR, DD>), dim3(grid), dim3(256), lds, ctx->stream, x, y, A->n_rows, A->n_cols, \
-                                               sw->n_blocks, remap_arg, w, partials, stop, sw->hdr, sw->slice_chunk0, stream, x_al16, own)
+                                               sw->n_blocks, remap_arg, w, partials, stop, sw->hdr, sw->slice_chunk0, stream, x_al16, own, sw->row_of)
 #define W8_L2(MODE, RR) do { if (depth <= 1) W8_L3(MODE, RR, 1); else if (depth == 2) W8_L3(MODE, RR, 2); else if (depth == 3) W8_L3(MODE, RR, 3); else if (depth <= 5) W8_L3(MODE, RR, 4); else W8_L3(MODE, RR, 6); } while (0)
 #define W8_L1(MODE) do { if (sw->R == 4) W8_L2(MODE, 4); else if (sw->R == 2) W8_L2(MODE, 2); else W8_L2(MODE, 1); } while (0)
     if (mode == 1) W8_L1(1); else W8_L1(0);

@@ -184,5 +184,12 @@ def test_bench_distributed_code_path_at_one_rank_agrees_with_the_plain_one():
     if dist["transport"].startswith("rccl"):
         assert dist["rccl_ranks_seen"] == 1
     assert plain["roofline"]["spmv_stream"]["val_bytes"] == 8 and dist["per_rank"][0]["spmv_stream"]["val_bytes"] == 8
-    ratio = dist["value"] / plain["value"]
-    assert 0.97 <= ratio <= 1.03, (plain["value"], dist["value"])
+    # The SpMV kernel itself has two placement levels 13 % apart (where its stream lies in HBM: DESIGN.md section 4; the library
+    # searches, but two processes need not end on the same level), so the comparison is made on what the partitioned path ADDS:
+    # its iteration time beyond its own SpMV time must not exceed the plain path's by more than 3 % of an iteration ...
+    over_plain = plain["ms_per_step"] - plain["roofline"]["avg_launch_ms"]
+    over_dist = dist["ms_per_step"] - dist["per_rank"][0]["spmv_ms_per_iter"]
+    assert over_dist <= over_plain + 0.03 * plain["ms_per_step"], (plain["ms_per_step"], plain["roofline"]["avg_launch_ms"], dist["ms_per_step"], dist["per_rank"][0]["spmv_ms_per_iter"])
+    # ... its SpMV (three launches over row views) must be within the placement spread of the plain one, and the rates within it too
+    assert dist["per_rank"][0]["spmv_ms_per_iter"] <= 1.16 * plain["roofline"]["avg_launch_ms"]
+    assert 0.86 <= dist["value"] / plain["value"] <= 1.16, (plain["value"], dist["value"])
