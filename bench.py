@@ -313,13 +313,18 @@ def target_512(ctx, steps=10, warmup=3):
     return rec
 
 
-def unstructured_spmv(ctx, launches=20):
-    """BASELINE config 5's SpMV: the CRS row-block kernel on the unstructured stand-in (fem:80,80,80 -- the size the
-    PMC passes of tools/spmv_pmc.sh profile; rows of 18-81 entries, more than 256 distinct values: no dictionary),
-    HIP-event timed."""
-    A = ctx.gen_fem(80, 80, 80)
-    N = A.n_rows
+def unstructured_spmv(ctx, launches=20, rcm=False):
+    """BASELINE config 5's SpMV, HIP-event timed: the stand-in with a grid (fem:80,80,80 -- the size the PMC passes of
+    tools/spmv_pmc.sh profile; rows of 18-81 entries, more than 256 distinct values: no dictionary), or (rcm=True) the
+    unstructured input as a real mesh is multiplied: unstr:80,80,80 RCM-ordered."""
     import numpy as np
+    if rcm:
+        A0 = ctx.gen_unstr(80, 80, 80)
+        A = ctx.permute(A0, ctx.bfs_order(A0, rcm=True))
+        A0.free()
+    else:
+        A = ctx.gen_fem(80, 80, 80)
+    N = A.n_rows
     x, y = ctx.upload(np.random.default_rng(12345).uniform(-1, 1, N)), ctx.alloc(N)
     for _ in range(3):
         ctx.spmv(A, x, y)
@@ -330,8 +335,9 @@ def unstructured_spmv(ctx, launches=20):
     ctx.sync()
     ctx.profile(False)
     n, ms = ctx.profile_read()
-    rec = {"workload": "fem:80,80,80 (stand-in for Flan_1565), y = A x", "rows": N, "nnz": A.nnz,
-           "roofline": spmv_roofline(A, ms * 1e-3 / max(n, 1), n, os.path.join(ROOT, "profiles", "spmv_traffic_fem.json"), 80)}
+    rec = {"workload": ("unstr:80,80,80 RCM-ordered (config 5 as named, the order a mesh is solved in), y = A x" if rcm else
+                        "fem:80,80,80 (stand-in for Flan_1565), y = A x"), "rows": N, "nnz": A.nnz,
+           "roofline": spmv_roofline(A, ms * 1e-3 / max(n, 1), n, os.path.join(ROOT, "profiles", "spmv_traffic_unstr_rcm.json" if rcm else "spmv_traffic_fem.json"), 80)}
     A.free(); x.free(); y.free()
     return rec
 
@@ -804,13 +810,14 @@ def main():
         if info["hbm_bytes"] >= 200e9:
             out["target_512"] = target_512(ctx)
             out["config5_spmv"] = unstructured_spmv(ctx)
+            out["config5_spmv_rcm"] = unstructured_spmv(ctx, rcm=True)
     if n1 == 256 and not args.no_sweeps:
         out["sweeps"] = sweep_legs(ctx)
         if not args.no_cpu_baseline:
             out["cpu_baseline_sptrsv"] = cpu_sptrsv_leg()
     out["options"] = ctx.options()
     out["options"]["placement_tuning"] = ("bis_mat_tune_placement: %d trials" % args.tune_placement) if args.tune_placement > 0 else \
-        "off (first allocation kept: boxes of the pool differ by 2-8 %, DESIGN.md section 6)"
+        "bis_mat_tune_placement off; the library's own build-time search on the win8 stream is on (roofline.placement_search; option spmv_win8_tune)"
     ctx.close()  # (the child processes below get the whole device)
     if n1 == 256 and not args.no_configs:
         out["configs"] = config_legs()

@@ -11,7 +11,12 @@ lib = load_library()
 if len(sys.argv) > 4:
     lib.bis_set_option(b"spmv_valdict", int(sys.argv[4]))
 ctx = Context(0)
-A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_fem(n1) if kind == "fem" else ctx.gen_anderson(n1)
+if kind == "unstr_rcm":  # config 5 as a real mesh is multiplied
+    A0 = ctx.gen_unstr(n1)
+    A = ctx.permute(A0, ctx.bfs_order(A0, rcm=True))
+    A0.free()
+else:
+    A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_fem(n1) if kind == "fem" else ctx.gen_anderson(n1)
 x, y = ctx.alloc(A.n_rows), ctx.alloc(A.n_rows)
 x.set(np.random.default_rng(0).uniform(-1, 1, A.n_rows))
 for _ in range(reps):
