@@ -1249,7 +1249,7 @@ bis_status bis_spmv_sellwin_launch(bis_ctx *ctx, const bis_mat *A, const double 
 // lossless re-layout of val, built on the device at the first SpMV and dropped when values change).
 // Usable by any matrix whose blocks of 256 R rows read at most 64 runs / 60 KB of x (runs a few granules apart are merged: banded /
 // stencil orderings, RCM-ordered meshes); the rows of a block are taken in order of their length (w8_plan_kernel), so rows of
-// very different lengths do not pad each other (still refused beyond 30 % padding).
+// very different lengths do not pad each other (refused beyond 12 % padding).
 namespace {
 
 constexpr int kW8ChunkBytes = 2560;
