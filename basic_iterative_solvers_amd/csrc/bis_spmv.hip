@@ -1234,7 +1234,7 @@ static bool win8_wanted() { return bis_opts().spmv_win8 != 0 && (bis_opts().spmv
 static bis_status launch_win8(bis_ctx *ctx, const bis_mat *A, const SpmvArgs &a, const double *x, double *y, int mode,
                               const double *w, double *partials, size_t partials_off, int *n_partials, bool *done) {
     *done = false;
-    if (mode == 2 || !win8_wanted()) return BIS_OK;
+    if (mode == 2 || !win8_wanted() || a.vcode) return BIS_OK; // (a matrix with a value dictionary keeps its dictionary kernels: 3 bytes per non-zero)
     if (bis_status st = bis_spmv_win8_try(ctx, const_cast<bis_mat *>(A))) return st;
     const int nbr = bis_spmv_win8_blocks(A);
     if (!nbr) return BIS_OK;
@@ -1425,7 +1425,7 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
         if (A->rm_state == 1) f = A->vd_diag ? 3 : 2;
     }
     if (!f && a.vcode && !a.vd_rm_only && spmv_variant(a) == 20 && a.pk_mode == 1) f = 1;
-    if (!f && win8_wanted() && A->n_rows > 0) { // form 6: window + sliced ELL, 8-byte values + 2-byte window slots
+    if (!f && !a.vcode && win8_wanted() && A->n_rows > 0) { // form 6: window + sliced ELL, 8-byte values + 2-byte window slots
         if (bis_status st = bis_spmv_win8_try(ctx, const_cast<bis_mat *>(A))) return st;
         if (bis_spmv_win8_blocks(A)) f = 6;
     }
