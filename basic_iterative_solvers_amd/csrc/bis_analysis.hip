@@ -45,6 +45,10 @@ __global__ __launch_bounds__(256) void level_kernel(const RP *__restrict__ row_p
             const int64_t r = valid ? (BACKWARD ? n - 1 - i : i) : 0;
             int64_t k = valid ? (int64_t)row_ptr[r] : 0;
             const int64_t e = valid ? (int64_t)row_ptr[r + 1] : 0;
+            // entries are taken towards the diagonal (an upper row from its last entry down): with ascending columns the row that
+            // was finished last -- the one this row waits for -- is then in the LAST batch, and the trips to memory of the earlier
+            // batches overlap that wait instead of following it (RCM-ordered 1.5 M rows, 7119 levels: 97 -> 2x ms backward)
+            const int64_t mirror = k + e - 1;
             int lvl = 0;
             bool bad = false, lost = false, done = false;
             unsigned spins = 0;
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void level_kernel(const RP *__restrict__ row_p
                         in_batch = e - k < (int64_t)kLvBatch ? (int)(e - k) : kLvBatch;
 #pragma unroll
                         for (int j = 0; j < kLvBatch; ++j) {
-                            pc[j] = j < in_batch ? col[k + j] : 0;
+                            pc[j] = j < in_batch ? col[BACKWARD ? mirror - (k + j) : k + j] : 0;
                             if (j < in_batch) {
                                 const bool side = BACKWARD ? pc[j] > r : pc[j] < r;
                                 if (pc[j] < 0 || pc[j] >= n || !side) { bad = true; pc[j] = -1; }

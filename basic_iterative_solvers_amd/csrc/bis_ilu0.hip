@@ -423,6 +423,7 @@ bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot
         if (hipGetLastError() != hipSuccess) { ctx->err = "bis_mat_ilu0: level launch failed"; st = BIS_ERR_HIP; }
     }
     if (st == BIS_OK) st = bis_mat_split_strict_impl(ctx, W, Ls_out, Us_out, nullptr, nullptr, false);
+    if (st == BIS_OK) bis_trsv_plan_adopt(*Ls_out, Lp, false); // same pattern: L's forward sweep starts from the levels found above
     bis_mat_destroy(ctx, Lp);
     bis_mat_destroy(ctx, Up);
     return cleanup(st);

@@ -342,6 +342,10 @@ void bis_mat_free_meta(bis_mat *A);
 // after the values of A changed in place: drops every structure derived from them (dictionaries, code streams, sweep plans)
 void bis_mat_values_changed(bis_mat *A);
 void bis_trsv_plan_destroy(bis_trsv_plan *p);
+// `to` has the sparsity pattern of `from` (ILU(0): the factor L and the strict lower triangle of A the elimination was scheduled
+// by): it takes over from's level plan (levels, level-sorted rows) instead of analysing the same pattern again.  No-op when
+// from has none, to has one, or the plan refers to from's storage (row views).
+void bis_trsv_plan_adopt(bis_mat *to, bis_mat *from, bool backward);
 bis_status bis_mat_split_strict_impl(bis_ctx *ctx, const bis_mat *A, bis_mat **L_strict,
                                      bis_mat **U_strict, double *D, double *D_inv, bool check_diag);
 // tiled natural-order sweep (bis_trsv_tiled.hip); *out stays null when the matrix does not qualify

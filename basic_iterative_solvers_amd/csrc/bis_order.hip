@@ -22,25 +22,73 @@
 
 namespace {
 
-// status[0] |= 1 if some entry (r,c), c != r, has no mirror (c,r)
+// status[0] |= 1 if some entry (r,c), c != r, has no mirror (c,r), or a row holds a column twice; deg[r] = entries off the diagonal.
+//
+// One WAVE per row.  Only the entries BELOW the diagonal are looked up (all 64 lanes read the mirrored row's columns at once: one
+// coalesced request per 64 entries instead of a lane walking the row alone, four entries' requests in flight), and the rows
+// count their entries below and above the diagonal into status[6..7] (one 64-bit balance): without repeated entries the mirrors of
+// the lower entries are distinct upper entries, so "every lower entry has its mirror" + "as many upper as lower entries" is
+// structural symmetry.  unstr:80,80,80 (1.04e8 entries, no locality): 69 ms with a lane per row and every entry looked up.
 template <typename RP>
 __global__ __launch_bounds__(256) void symmetry_kernel(const RP *__restrict__ row_ptr, const int32_t *__restrict__ col, int64_t n,
                                                        int *__restrict__ deg, int *status) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return; // (wave-uniform)
+    const int64_t s = (int64_t)row_ptr[r], e = (int64_t)row_ptr[r + 1];
     bool bad = false;
     int d = 0;
-    for (int64_t k = (int64_t)row_ptr[r]; k < (int64_t)row_ptr[r + 1]; ++k) {
-        const int64_t c = col[k];
-        if (c == r) continue;
-        ++d;
-        bool found = false;
-        for (int64_t q = (int64_t)row_ptr[c]; q < (int64_t)row_ptr[c + 1] && !found; ++q) found = col[q] == r;
-        bad |= !found;
-        for (int64_t q = (int64_t)row_ptr[r]; q < k; ++q) bad |= col[q] == c; // a repeated entry: the degrees would differ from the host's
+    long long balance = 0;
+    for (int64_t base = s; base < e; base += 64) {
+        const int cnt = e - base < 64 ? (int)(e - base) : 64;
+        const int c_mine = lane < cnt ? col[base + lane] : -1;
+        const bool lower = c_mine >= 0 && (int64_t)c_mine < r;
+        d += __popcll(__ballot(c_mine >= 0 && (int64_t)c_mine != r));
+        balance += (long long)__popcll(__ballot(lower)) - (long long)__popcll(__ballot((int64_t)c_mine > r));
+        // a column twice in the row: among the entries of this chunk, and against the chunks before it
+        for (int j = 1; j < cnt; ++j) {
+            const int c = __shfl(c_mine, j);
+            bad |= (__ballot(c_mine == c) & ((1ull << j) - 1ull)) != 0ull;
+        }
+        for (int64_t q = s; q < base; q += 64) {
+            const int w = col[q + lane];
+            for (int j = 0; j < cnt; ++j) bad |= __ballot(w == __shfl(c_mine, j)) != 0ull;
+        }
+        // mirrors of the lower entries
+        int64_t qs = 0;
+        int ql = 0;
+        if (lower) { qs = (int64_t)row_ptr[c_mine]; ql = (int)((int64_t)row_ptr[c_mine + 1] - qs); }
+        const unsigned long long todo = __ballot(lower);
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+            if (((todo >> j0) & 0xFull) == 0ull) continue;
+            int v[4], len[4];
+            int64_t start[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = (j0 + u) & 63;
+                on[u] = j0 + u < 64 && ((todo >> j) & 1ull) != 0ull;
+                start[u] = __shfl(qs, j);
+                len[u] = on[u] ? __shfl(ql, j) : 0;
+                v[u] = lane < len[u] ? col[start[u] + lane] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!on[u]) continue;
+                bool found = __ballot((int64_t)v[u] == r) != 0ull;
+                for (int q = 64; q < len[u] && !found; q += 64) {
+                    const int w = q + lane < len[u] ? col[start[u] + q + lane] : -1;
+                    found = __ballot((int64_t)w == r) != 0ull;
+                }
+                bad |= !found;
+            }
+        }
     }
-    deg[r] = d;
-    if (bad) atomicOr(status, 1);
+    if (lane == 0) {
+        deg[r] = d;
+        if (bad) atomicOr(status, 1);
+        if (balance != 0) atomicAdd((unsigned long long *)(status + 6), (unsigned long long)balance);
+    }
 }
 
 __global__ __launch_bounds__(256) void degree_keys_kernel(const int *__restrict__ deg, int64_t n, unsigned long long *keys, int32_t *ids) {
@@ -259,10 +307,11 @@ bis_status bfs_order_t(bis_ctx *ctx, const bis_mat *A, bool rcm, int32_t *perm_d
     BIS_OR_CHECK(hipMalloc(&keys_out, 8 * n1));
     BIS_OR_CHECK(hipMemsetAsync(status, 0, sizeof(int) * 8, ctx->stream));
     if (n == 0) return cleanup(BIS_OK);
-    hipLaunchKernelGGL(symmetry_kernel<RP>, dim3(n_blk), dim3(256), 0, ctx->stream, rp, A->col, n, deg, status);
-    int h = 0;
-    BIS_OR_CHECK(hipMemcpyAsync(&h, status, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(symmetry_kernel<RP>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, rp, A->col, n, deg, status);
+    int hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    BIS_OR_CHECK(hipMemcpyAsync(hs, status, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
     BIS_OR_CHECK(hipStreamSynchronize(ctx->stream));
+    const int h = hs[0] | (hs[6] != 0) | (hs[7] != 0); // [6..7]: entries below minus entries above the diagonal
     if (h) { ctx->err = "bis_mat_bfs_order: pattern is not structurally symmetric (or has repeated entries): use the host ordering"; return cleanup(BIS_ERR_UNSUPPORTED); }
     auto sort_pairs = [&](unsigned long long *k_in, unsigned long long *k_out, int32_t *v_in, int32_t *v_out, size_t m) -> hipError_t {
         size_t bytes = 0;

@@ -69,6 +69,15 @@ void bis_trsv_plan_destroy(bis_trsv_plan *p) {
     delete p;
 }
 
+void bis_trsv_plan_adopt(bis_mat *to, bis_mat *from, bool backward) {
+    if (!to || !from || to == from) return;
+    bis_trsv_plan *&src = backward ? from->plan_bwd : from->plan_fwd;
+    bis_trsv_plan *&dst = backward ? to->plan_bwd : to->plan_fwd;
+    if (!src || dst || !src->level_views.empty() || to->n_rows != from->n_rows || to->nnz != from->nnz || to->rp64 != from->rp64) return;
+    dst = src;
+    src = nullptr;
+}
+
 namespace {
 
 constexpr unsigned long long kSentinel = 0x7FF85EA71E55C0DEull; // quiet NaN + payload

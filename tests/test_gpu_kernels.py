@@ -1060,6 +1060,58 @@ def test_device_bfs_refuses_unsymmetric_patterns_and_bad_permutations(ctx):
         ctx.permute(dA, np.array([0, 0, 2], dtype=np.int32))
 
 
+def _crs_from_rows(rows):
+    rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    col = np.concatenate([np.asarray(r, dtype=np.int64) for r in rows]) if rp[-1] else np.zeros(0, np.int64)
+    return CRS(len(rows), rp.astype(np.int32), col.astype(np.int32), np.ones(len(col)))
+
+
+def test_device_symmetry_check_long_rows_and_compensating_defects(ctx):
+    """The structure check of bis_mat_bfs_order (a wave per row: mirrors of the entries below the diagonal looked up 64
+    columns at a time + a count of the entries on both sides): rows of several 64-entry chunks with columns in any order
+    pass; a missing mirror in a late chunk, a missing mirror balanced by a stray entry elsewhere (the counts agree), and a
+    column repeated inside a chunk or across two chunks are all refused."""
+    from basic_iterative_solvers_amd import BisError
+    rng = np.random.default_rng(3)
+    n = 300
+    dense = rng.random((n, n)) < 0.6
+    dense = dense | dense.T
+    np.fill_diagonal(dense, True)
+    rows = [rng.permutation(np.flatnonzero(dense[r])).tolist() for r in range(n)]  # ~230 entries per row, unsorted
+    A = _crs_from_rows(rows)
+    dA = ctx.matrix(A)
+    assert np.array_equal(ctx.bfs_order(dA, True), _queue_order(A, True))
+    dA.free()
+
+    def refused(rows2):
+        d = ctx.matrix(_crs_from_rows(rows2))
+        with pytest.raises(BisError, match="structurally symmetric"):
+            ctx.bfs_order(d)
+        d.free()
+
+    # the mirror (5, 290) of a lower entry sitting in row 290's last chunk is gone
+    r2 = [list(r) for r in rows]
+    lower = [c for c in r2[290] if c < 290]
+    victim = r2[290][-1] if r2[290][-1] < 290 else lower[-1]
+    r2[victim] = [c for c in r2[victim] if c != 290]
+    refused(r2)
+    # ... and with a stray upper entry somewhere else the counts on both sides of the diagonal agree again
+    free_col = next(c for c in range(n - 1, 0, -1) if c not in r2[0] and c != victim)
+    r3 = [list(r) for r in r2]
+    r3[0] = r3[0] + [free_col]
+    refused(r3)
+    # a column twice: inside one chunk, and in two different chunks of a long row
+    r4 = [list(r) for r in rows]
+    r4[7] = r4[7][:3] + [r4[7][1]] + r4[7][3:]
+    refused(r4)
+    r5 = [list(r) for r in rows]
+    assert len(r5[200]) > 140
+    r5[200] = r5[200] + [r5[200][2]]  # first chunk's column again in the last chunk
+    refused(r5)
+    # small: lower entry without a mirror, balanced by an upper entry without one
+    refused([[0, 2], [0, 1], [2]])
+
+
 _PCG_KEYS = sorted(k for k in _H if k.split("|")[1] == "cg" and k.split("|")[2] in ("sgs", "ilu0", "s2st", "j")
                    and "num_scale" not in k)
 
