@@ -326,26 +326,51 @@ __global__ __launch_bounds__(kSplitT) void split_fill_kernel(
         su[threadIdx.x] += au;
         __syncthreads();
     }
-    if (r >= n_rows) return;
-    int64_t pl = blk_l[blockIdx.x] + sl[threadIdx.x] - cl;
-    int64_t pu = blk_u[blockIdx.x] + su[threadIdx.x] - cu;
-    rpL[r] = (RPO)pl;
-    rpU[r] = (RPO)pu;
-    if (r == n_rows - 1) { rpL[n_rows] = (RPO)(pl + cl); rpU[n_rows] = (RPO)(pu + cu); }
-    bool have_diag = false;
-    for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
-        const int64_t c = col[k];
-        const double v = val[k];
-        if (c < g) { colL[pl] = (int32_t)c; valL[pl++] = v; }
-        else if (c > g) { colU[pu] = (int32_t)c; valU[pu++] = v; }
-        else { // peel_diag_crs keeps the LAST diagonal entry it meets (:843-857)
-            have_diag = true;
-            if (D) D[r] = v;
-            if (D_inv) D_inv[r] = 1.0 / v;
-            if (fabs(v) < 1e-16) atomicMin(status, ((unsigned long long)(g + 1) << 1) | 0ull);
+    {
+        const int64_t pl = blk_l[blockIdx.x] + sl[threadIdx.x] - cl;
+        const int64_t pu = blk_u[blockIdx.x] + su[threadIdx.x] - cu;
+        __syncthreads();
+        sl[threadIdx.x] = pl; // (from here on: where the row's entries go)
+        su[threadIdx.x] = pu;
+        if (r < n_rows) {
+            rpL[r] = (RPO)pl;
+            rpU[r] = (RPO)pu;
+            if (r == n_rows - 1) { rpL[n_rows] = (RPO)(pl + cl); rpU[n_rows] = (RPO)(pu + cu); }
         }
+        __syncthreads();
     }
-    if (!have_diag) atomicMin(status, ((unsigned long long)(g + 1) << 1) | 1ull);
+    // the entries: a WAVE per row, 64 entries at a time (coalesced reads and writes; a lane walking its row alone moved
+    // 1.25 GB in 6.7 ms); positions inside L and U from the ballots, so the order inside a row is kept
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int t = wave; t < kSplitT; t += kSplitT / 64) {
+        const int64_t rr = (int64_t)blockIdx.x * kSplitT + t;
+        if (rr >= n_rows) break; // (wave-uniform)
+        const int64_t gg = row0 + rr;
+        int64_t pl = sl[t], pu = su[t];
+        bool have_diag = false;
+        const int64_t e = (int64_t)row_ptr[rr + 1];
+        for (int64_t base = (int64_t)row_ptr[rr]; base < e; base += 64) {
+            const int64_t k = base + lane;
+            const bool in = k < e;
+            const int64_t c = in ? (int64_t)col[k] : gg;
+            const double v = in ? val[k] : 0.0;
+            const unsigned long long mL = __ballot(in && c < gg), mU = __ballot(in && c > gg), mD = __ballot(in && c == gg);
+            if (in && c < gg) { const int64_t q = pl + __popcll(mL & below); colL[q] = (int32_t)c; valL[q] = v; }
+            if (in && c > gg) { const int64_t q = pu + __popcll(mU & below); colU[q] = (int32_t)c; valU[q] = v; }
+            pl += __popcll(mL);
+            pu += __popcll(mU);
+            if (mD) { // peel_diag_crs keeps the LAST diagonal entry it meets (:843-857); every one of them is tested
+                have_diag = true;
+                if (in && c == gg && fabs(v) < 1e-16) atomicMin(status, ((unsigned long long)(gg + 1) << 1) | 0ull);
+                if (lane == 63 - __builtin_clzll(mD)) {
+                    if (D) D[rr] = v;
+                    if (D_inv) D_inv[rr] = 1.0 / v;
+                }
+            }
+        }
+        if (!have_diag && lane == 0) atomicMin(status, ((unsigned long long)(gg + 1) << 1) | 1ull);
+    }
 }
 
 template <typename RP>

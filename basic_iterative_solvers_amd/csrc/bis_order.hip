@@ -208,13 +208,30 @@ __global__ __launch_bounds__(256) void pm_fill_kernel(const RP *__restrict__ row
         sc[threadIdx.x] += v;
         __syncthreads();
     }
-    if (i >= n) return;
-    const int64_t p = blk[blockIdx.x] + sc[threadIdx.x] - len;
-    rpB[i] = (RP)p;
-    if (i == n - 1) rpB[n] = (RP)(p + len);
-    for (int q = 0; q < len; ++q) { // entries keep their order inside the row
-        colB[p + q] = inv[col[a + q]];
-        valB[p + q] = val[a + q];
+    __shared__ int64_t sa[256];
+    __shared__ int sn[256];
+    {
+        const int64_t p = blk[blockIdx.x] + sc[threadIdx.x] - len;
+        __syncthreads();
+        sc[threadIdx.x] = p; // (from here on: where the row's entries go)
+        sa[threadIdx.x] = a;
+        sn[threadIdx.x] = len;
+        if (i < n) {
+            rpB[i] = (RP)p;
+            if (i == n - 1) rpB[n] = (RP)(p + len);
+        }
+        __syncthreads();
+    }
+    // the entries, a WAVE per row (coalesced on both sides; entries keep their order inside the row)
+    const int lane = threadIdx.x & 63;
+    for (int t = threadIdx.x >> 6; t < 256; t += 4) {
+        if ((int64_t)blockIdx.x * 256 + t >= n) break; // (wave-uniform)
+        const int64_t src = sa[t], dst = sc[t];
+        const int ln = sn[t];
+        for (int q = lane; q < ln; q += 64) {
+            colB[dst + q] = inv[col[src + q]];
+            valB[dst + q] = val[src + q];
+        }
     }
 }
 __global__ __launch_bounds__(256) void invert_kernel(const int32_t *__restrict__ perm, int64_t n, int32_t *__restrict__ inv, int *status) {
