@@ -403,6 +403,13 @@ class Mat:
         self.ctx.lib.bis_mat_win8_tuning(self.h, C.byref(t), C.byref(a), C.byref(b))
         return t.value, a.value, b.value
 
+    def colslab_info(self):
+        """(K, one-pass ms, K-passes ms): the column slabs the SpMV of this matrix runs on (0: none) and the build-time trial's
+        times (bis_mat_colslab_info)."""
+        k, a, b = C.c_int(), C.c_double(), C.c_double()
+        self.ctx.lib.bis_mat_colslab_info(self.h, C.byref(k), C.byref(a), C.byref(b))
+        return k.value, a.value, b.value
+
     def sweep_kernel(self, backward=False):
         """Name of the kernel the last forward / backward sweep on this triangle ran (bis_mat_sweep_kernel)."""
         return self.ctx.lib.bis_mat_sweep_kernel(self.h, C.c_int(int(backward))).decode()

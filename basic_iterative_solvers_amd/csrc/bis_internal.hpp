@@ -101,6 +101,7 @@ struct bis_options {
     int spmv_sellwin_rows = -1; // rows per lane of the sliced-ELL form: 1 or 2 (blocks of 256 or 512 rows; -1: default 2)
     int spmv_sellwin_pairs = -1; // 0: never the one-byte (column - row, value) pair codes
     int spmv_sellwin_joint = -1; // 0: never the 16-bit joint (slot, value) codes
+    int spmv_colslab = -1;     // column slabs for matrices without locality (bis_spmv_slab.hip): 0 never, -1 where a build-time trial measures them faster, k >= 2: k slabs wherever the plan applies (tests)
     int spmv_win8 = -1;        // window + sliced-ELL SpMV with the 8-byte values streamed (matrices without a dictionary form, or with spmv_valdict = 0): 0 off, 1 on where its plan applies (-1: default = on)
     int spmv_win8_rows = -1;   // ... rows per lane: 1, 2 or 4 (blocks of 256, 512, 1024 rows; default 2)
     int spmv_win8_depth = -1;  // ... chunks requested ahead per lane: 1, 2, 3, 4 or 6 (default by block size)
@@ -177,6 +178,9 @@ struct bis_mat {
     int sw_state = 0;
     // the same plan with the 8-byte values streamed (no dictionary needed): "win8", bis_spmv_sell.hip; state as above
     struct bis_sellwin *sw8 = nullptr;
+    std::vector<bis_mat *> *colslabs = nullptr; // column slabs of a matrix without locality (bis_spmv_slab.hip); cs_state: 0 untried, 1 in use, -1 refused
+    int cs_state = 0;
+    double cs_trial_ms[2] = {0.0, 0.0};        // the build-time trial: one pass / the K passes
     int sw8_state = 0;
     // second table for the SpMV with the fused (y,w) epilogue (CG): larger blocks win there
     int32_t *blkf_row = nullptr;
@@ -331,6 +335,9 @@ int64_t bis_spmv_win8_bytes(const bis_mat *A);
 bis_status bis_spmv_win8_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y, int mode, const double *w,
                                 double *partials, const int *stop, int remap_arg, int grid);
 void bis_spmv_win8_drop(bis_mat *A);
+bis_status bis_spmv_colslab_build(bis_ctx *ctx, const bis_mat *A, int K, std::vector<bis_mat *> &slabs, bool *ok);
+void bis_spmv_colslab_free(bis_ctx *ctx, std::vector<bis_mat *> &slabs);
+void bis_spmv_colslab_drop(bis_mat *A);
 int bis_spmv_remap_arg(int nb);
 int bis_spmv_grid(int nb);
 size_t bis_spmv_win8_stream_bytes(const bis_mat *A);

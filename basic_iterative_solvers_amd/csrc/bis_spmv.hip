@@ -104,7 +104,7 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     const double *__restrict__ val, const double *x, double *y,
     const int32_t *__restrict__ blk_row, const int64_t *__restrict__ blk_nnz, int n_blocks,
     int n_blocks_pad8, const double *w, double *partials, const uint16_t *__restrict__ pk,
-    int64_t pk_base, const int32_t *__restrict__ seg_base, int col_max, const int *stop) {
+    int64_t pk_base, const int32_t *__restrict__ seg_base, int col_max, const int *stop, int acc_y) {
     constexpr bool FUSE_DOT = MODE == 1;
     if (stop && stop[1]) return; // the solver has stopped: this launch is a no-op
     extern __shared__ __attribute__((aligned(16))) double prod[];
@@ -255,7 +255,9 @@ __global__ __launch_bounds__(T) void spmv_rowblock_kernel(
     for (int r = my_r; r < r1; r += T) {
         if (r != my_r) { rp_a = row_ptr[r]; rp_z = row_ptr[r + 1]; }
         const int a = (int)((int64_t)rp_a - s4), z = (int)((int64_t)rp_z - s4);
-        double acc = 0.0;
+        // (acc_y: this launch is a later column slab of the matrix -- bis_spmv_slab.hip -- and continues the row's sum where the
+        // slab before it left it in y)
+        double acc = (MODE != 2 && acc_y) ? y[r] : 0.0;
         for (int j = a; j < z; ++j) acc += prod[j];
         if (MODE == 2) y[r] = (w[r] - acc) / partials[r];
         else y[r] = acc;
@@ -840,6 +842,7 @@ struct SpmvArgs {
     const int *stop = nullptr;
     const uint8_t *vcode = nullptr; int64_t vd_base = 0; const double *vdict = nullptr; // value dictionary (pk_mode 1 only)
     bool vd_rm_only = false; // lane-per-row kernel only
+    int acc_y = 0;           // row sums start from y (a later column slab)
 };
 
 template <typename RP, int T, int U, int BR = 0>
@@ -847,7 +850,7 @@ void launch_variant(const SpmvArgs &a) {
 #define BIS_LV(PK, MODE)                                                                          \
     hipLaunchKernelGGL((spmv_rowblock_kernel<RP, T, U, (PK) < 0 ? 0 : (PK), MODE, (PK) < 0, BR>), dim3(a.grid), dim3(T), a.lds_bytes, \
                        a.stream, (const RP *)a.row_ptr, a.col, a.val, a.x, a.y, a.blk_row, a.blk_nnz, \
-                       a.nb, a.remap_arg, a.w, a.partials, a.pk, a.pk_base, a.seg_base, a.col_max, a.stop)
+                       a.nb, a.remap_arg, a.w, a.partials, a.pk, a.pk_base, a.seg_base, a.col_max, a.stop, a.acc_y)
 #define BIS_LVM(PK)                                                                               \
     do {                                                                                          \
         if (a.mode == 2) BIS_LV(PK, 2);                                                           \
@@ -874,7 +877,7 @@ void launch_vd(const SpmvArgs &a) {
 
 template <typename RP>
 bool launch_by_id(int id, const SpmvArgs &a) {
-    if (a.vcode && !a.vd_rm_only && id == 20 && a.pk_mode == 1) { // value dictionary, consecutive form: the default variant only
+    if (a.vcode && !a.acc_y && !a.vd_rm_only && id == 20 && a.pk_mode == 1) { // value dictionary, consecutive form: the default variant only
         if (a.mode == 2) launch_vd<RP, 2>(a);
         else if (a.mode == 1) launch_vd<RP, 1>(a);
         else launch_vd<RP, 0>(a);
@@ -980,6 +983,7 @@ void bis_spmv_drop_valdict(bis_mat *A) {
     A->rm_nnz = nullptr; A->rm_pk = nullptr; A->rm_seg = nullptr; A->rm_state = 0; A->rm_blocks = 0;
     bis_spmv_sellwin_drop(A);
     bis_spmv_win8_drop(A);
+    bis_spmv_colslab_drop(A);
 }
 
 // the 256-row blocks of the lane-per-row form and their packed column stream; rm_state tells the outcome
@@ -1290,6 +1294,126 @@ static bis_status launch_rowmajor(bis_ctx *ctx, const bis_mat *A, const SpmvArgs
     return BIS_OK;
 }
 
+// ---- column slabs (bis_spmv_slab.hip): K passes of the row-block kernel, each gathering from an x slice that fits the L2 ----
+
+void bis_spmv_colslab_drop(bis_mat *A) {
+    if (A->colslabs) {
+        for (bis_mat *B : *A->colslabs) { // (no context at hand: what bis_mat_destroy does for a matrix that owns its arrays)
+            bis_mat_free_meta(B);
+            hipFree(B->row_ptr); hipFree(B->col); hipFree(B->val);
+            delete B;
+        }
+        delete A->colslabs;
+        A->colslabs = nullptr;
+    }
+    A->cs_state = 0;
+    A->cs_trial_ms[0] = A->cs_trial_ms[1] = 0.0;
+}
+
+// one pass of the row-block kernel over matrix B (A itself, or one of its slabs)
+static bis_status rowblock_pass(bis_ctx *ctx, const bis_mat *B, const double *x, double *y, const double *w, size_t partials_off,
+                                int acc_y, const int *stop, int *n_partials) {
+    const bool use_f = w != nullptr;
+    const int64_t lds_doubles = (int64_t)(use_f ? B->chunk_f : B->chunk_nnz) + B->max_row_nnz + 8;
+    const int nb = use_f ? B->n_blocks_f : B->n_blocks, nb8 = (nb + 7) & ~7;
+    if (w && partials_off + (size_t)nb * 4 > ctx->partials_cap) { ctx->err = "bis_spmv: partials buffer too small (internal)"; return BIS_ERR_INVALID; }
+    SpmvArgs a{B->row_ptr, B->col, B->val, x, y, use_f ? B->blkf_row : B->blk_row, use_f ? B->blkf_nnz : B->blk_nnz, nb, nb8, w,
+               ctx->partials + partials_off, sizeof(double) * (size_t)lds_doubles, ctx->stream, w ? 1 : 0};
+    a.n_cus = ctx->n_cus;
+    a.remap = bis_opts().spmv_xcd_remap == 1;
+    a.remap_arg = remap_arg_for(nb8);
+    a.grid = grid_for_map(nb, a.remap_arg);
+    if (bis_status st = ensure_packed(ctx, B, use_f ? 1 : 0, &a)) return st;
+    a.vcode = nullptr; // (the plain row-block kernel: the value-dictionary kernel has no accumulating form)
+    a.stop = stop;
+    a.acc_y = acc_y;
+    const bool ok = launch_by_id<int32_t>(spmv_variant(a), a);
+    if (!ok) { ctx->err = "bis_spmv: unknown BIS_SPMV_VARIANT"; return BIS_ERR_INVALID; }
+    if (w && n_partials) *n_partials = nb * (fused_threads(spmv_variant(a)) / 64);
+    return BIS_OK;
+}
+
+static bis_status colslab_passes(bis_ctx *ctx, const bis_mat *A, const double *x, double *y, const double *w, size_t partials_off,
+                                 const int *stop, int *n_partials) {
+    const std::vector<bis_mat *> &S = *A->colslabs;
+    for (size_t k = 0; k < S.size(); ++k) {
+        const bool last = k + 1 == S.size();
+        if (bis_status st = rowblock_pass(ctx, S[k], x, y, last ? w : nullptr, partials_off, k > 0 ? 1 : 0, stop, last ? n_partials : nullptr)) return st;
+    }
+    return BIS_OK;
+}
+
+// Builds the slabs where the plan applies: 32-bit row pointers, not a row view, rows of at most the LDS budget, a column stream
+// that did NOT pack (a matrix whose row blocks each touch at most 8 windows of 8192 columns has the locality the slabs would
+// make), an x of more than 6 MiB, ascending rows.  Default: K = x's bytes / 2 MiB (2..32) and a trial -- three timed launches of
+// the one pass and of the K passes on a scratch x -- keeps the slabs only where they are at least 15 % faster.
+static bis_status colslab_try(bis_ctx *ctx, bis_mat *A, bool packed) {
+    if (A->cs_state != 0) return BIS_OK;
+    A->cs_state = -1;
+    const int opt = bis_opts().spmv_colslab;
+    const bool forced = opt >= 2;
+    if (opt == 0 || A->rp64 || A->view || A->n_rows == 0 || A->nnz == 0) return BIS_OK;
+    if (!forced && (packed || 8 * A->n_cols <= (int64_t)6 << 20 || A->nnz < ((int64_t)1 << 22))) return BIS_OK;
+    if (sizeof(double) * (size_t)((int64_t)A->chunk_f + A->max_row_nnz + 8) > 64 * 1024) return BIS_OK;
+    int K = forced ? std::min(opt, 32) : (int)std::min<int64_t>(32, std::max<int64_t>(2, (8 * A->n_cols + ((int64_t)2 << 20) - 1) / ((int64_t)2 << 20)));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (int64_t)free_b < 16 * A->nnz + ((int64_t)8 << 30)) { (void)hipGetLastError(); return BIS_OK; }
+    auto *slabs = new std::vector<bis_mat *>();
+    bool ok = false;
+    bis_status st = bis_spmv_colslab_build(ctx, A, K, *slabs, &ok);
+    if (st != BIS_OK || !ok) { delete slabs; return st; }
+    A->colslabs = slabs;
+    if (!forced) { // the trial
+        double *xs = nullptr, *ys = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool good = hipMalloc(&xs, sizeof(double) * (size_t)A->n_cols) == hipSuccess && hipMalloc(&ys, sizeof(double) * (size_t)A->n_rows) == hipSuccess &&
+                    hipMemsetAsync(xs, 0, sizeof(double) * (size_t)A->n_cols, ctx->stream) == hipSuccess &&
+                    hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
+        float ms[2] = {0.f, 0.f};
+        for (int which = 0; which < 2 && good && st == BIS_OK; ++which) {
+            for (int rep = 0; rep < 5 && st == BIS_OK; ++rep) {
+                if (rep == 2) good = good && hipEventRecord(ev[0], ctx->stream) == hipSuccess;
+                st = which ? colslab_passes(ctx, A, xs, ys, nullptr, 0, nullptr, nullptr) : rowblock_pass(ctx, A, xs, ys, nullptr, 0, 0, nullptr, nullptr);
+            }
+            good = good && hipEventRecord(ev[1], ctx->stream) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess &&
+                   hipEventElapsedTime(&ms[which], ev[0], ev[1]) == hipSuccess;
+        }
+        if (ev[0]) hipEventDestroy(ev[0]);
+        if (ev[1]) hipEventDestroy(ev[1]);
+        hipFree(xs); hipFree(ys);
+        (void)hipGetLastError();
+        A->cs_trial_ms[0] = ms[0] / 3.0;
+        A->cs_trial_ms[1] = ms[1] / 3.0;
+        if (st != BIS_OK || !good || !(ms[1] < 0.85f * ms[0])) {
+            const double keep[2] = {A->cs_trial_ms[0], A->cs_trial_ms[1]};
+            bis_spmv_colslab_drop(A);
+            A->cs_state = -1;
+            A->cs_trial_ms[0] = keep[0]; A->cs_trial_ms[1] = keep[1];
+            return st;
+        }
+    }
+    A->cs_state = 1;
+    return BIS_OK;
+}
+
+static bool colslab_wanted(const SpmvArgs &a) {
+    return bis_opts().spmv_colslab != 0 && !a.vcode && !a.wide && (bis_opts().spmv_variant < 0 || bis_opts().spmv_variant == 20 || bis_opts().spmv_variant == 41);
+}
+static bis_status launch_colslab(bis_ctx *ctx, const bis_mat *A, const SpmvArgs &a, const double *x, double *y, const double *w,
+                                 size_t partials_off, int *n_partials, bool *done) {
+    *done = false;
+    if (!colslab_wanted(a)) return BIS_OK;
+    if (bis_status st = colslab_try(ctx, const_cast<bis_mat *>(A), a.pk_mode != 0)) return st;
+    if (A->cs_state != 1) return BIS_OK;
+    bis_prof_begin(ctx);
+    bis_status st = colslab_passes(ctx, A, x, y, w, partials_off, a.stop, n_partials);
+    bis_prof_end(ctx);
+    if (st != BIS_OK) return st;
+    BIS_HIP_CHECK(ctx, hipGetLastError());
+    *done = true;
+    return BIS_OK;
+}
+
 // internal: y = A x, optionally partials[b] = sum_{r in block b} y[r]*w[r]
 // (n_partials returns the number of partials written; 0 if not fused).
 bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, double *y,
@@ -1358,6 +1482,11 @@ bis_status bis_spmv_launch(bis_ctx *ctx, const bis_mat *A, const double *x, doub
     {
         bool done = false;
         if (bis_status st = launch_win8(ctx, A, a, x, y, w ? 1 : 0, w, ctx->partials, partials_off, n_partials, &done)) return st;
+        if (done) return BIS_OK;
+    }
+    {
+        bool done = false;
+        if (bis_status st = launch_colslab(ctx, A, a, x, y, w, partials_off, n_partials, &done)) return st;
         if (done) return BIS_OK;
     }
     if (bis_opts().spmv_lds_pad > 0) a.lds_bytes += (size_t)bis_opts().spmv_lds_pad;
@@ -1429,6 +1558,22 @@ bis_status bis_mat_spmv_stream_info(bis_ctx *ctx, const bis_mat *A, int *col_byt
         if (bis_status st = bis_spmv_win8_try(ctx, const_cast<bis_mat *>(A))) return st;
         if (bis_spmv_win8_blocks(A)) f = 6;
     }
+    if (!f && colslab_wanted(a) && A->n_rows > 0 && sizeof(double) * (size_t)lds_doubles <= 64 * 1024) { // form 7: K column slabs, each a pass of the row-block kernel
+        if (bis_status st = colslab_try(ctx, const_cast<bis_mat *>(A), a.pk_mode != 0)) return st;
+        if (A->cs_state == 1) {
+            bool all_packed = true;
+            for (const bis_mat *B : *A->colslabs) {
+                SpmvArgs b{};
+                if (bis_status st = ensure_packed(ctx, B, 0, &b)) return st;
+                all_packed = all_packed && (b.pk_mode != 0 || B->nnz == 0);
+            }
+            if (col_bytes) *col_bytes = all_packed ? 2 : 4;
+            if (val_bytes) *val_bytes = 8;
+            if (n_dict) *n_dict = (int)A->colslabs->size(); // (the number of slabs)
+            if (form) *form = 7;
+            return BIS_OK;
+        }
+    }
     if (f == 6) {
         if (col_bytes) *col_bytes = 2;
         if (val_bytes) *val_bytes = 8;
@@ -1450,7 +1595,11 @@ bis_status bis_mat_spmv_streamed_bytes(bis_ctx *ctx, const bis_mat *A, int64_t *
     if (bis_status st = bis_mat_spmv_stream_info(ctx, A, &col_b, &val_b, &n_dict, &form)) return st;
     const int64_t rp = A->rp64 ? 8 : 4;
     int64_t b = 8 * A->n_cols + 8 * A->n_rows; // x once, y once
-    if (form == 6) {
+    if (form == 7) { // the slabs' CRS copies, and y read and written again by every pass after the first
+        for (const bis_mat *B : *A->colslabs)
+            b += (int64_t)(col_b + val_b) * B->nnz + rp * (B->n_rows + 1) + (int64_t)B->n_blocks * (12 + (col_b == 2 ? 32 : 0));
+        b += 16 * A->n_rows * ((int64_t)A->colslabs->size() - 1);
+    } else if (form == 6) {
         b += bis_spmv_win8_bytes(A);
     } else if (form >= 4) {
         b += bis_spmv_sellwin_bytes(A);
@@ -1462,6 +1611,12 @@ bis_status bis_mat_spmv_streamed_bytes(bis_ctx *ctx, const bis_mat *A, int64_t *
     if (form == 3 || form == 5) b += 8 * A->n_rows; // the per-row diagonal values
     *bytes = b;
     return BIS_OK;
+}
+
+void bis_mat_colslab_info(const bis_mat *A, int *slabs, double *one_pass_ms, double *slab_passes_ms) {
+    if (slabs) *slabs = (A && A->cs_state == 1 && A->colslabs) ? (int)A->colslabs->size() : 0;
+    if (one_pass_ms) *one_pass_ms = A ? A->cs_trial_ms[0] : 0.0;
+    if (slab_passes_ms) *slab_passes_ms = A ? A->cs_trial_ms[1] : 0.0;
 }
 
 bis_status bis_compute_residual(bis_ctx *ctx, const bis_mat *A, const double *x, const double *b,

@@ -150,7 +150,8 @@ def measured_stream(ctx, N):
 
 
 KERNEL_OF_FORM = ("spmv_rowblock_kernel", "spmv_rowblock_vd_kernel", "spmv_rowmajor_vd_kernel", "spmv_rowmajor_vd_kernel",
-                  "spmv_sellwin_kernel", "spmv_sellwin_kernel", "spmv_win8_kernel")
+                  "spmv_sellwin_kernel", "spmv_sellwin_kernel", "spmv_win8_kernel",
+                  "spmv_rowblock_kernel (one pass per column slab)")
 
 
 def stream_format(A):
@@ -313,7 +314,7 @@ def target_512(ctx, steps=10, warmup=3):
     return rec
 
 
-def unstructured_spmv(ctx, launches=20, rcm=False):
+def unstructured_spmv(ctx, launches=20, rcm=False, asis=False):
     """BASELINE config 5's SpMV, HIP-event timed: the stand-in with a grid (fem:80,80,80 -- the size the PMC passes of
     tools/spmv_pmc.sh profile; rows of 18-81 entries, more than 256 distinct values: no dictionary), or (rcm=True) the
     unstructured input as a real mesh is multiplied: unstr:80,80,80 RCM-ordered."""
@@ -322,6 +323,8 @@ def unstructured_spmv(ctx, launches=20, rcm=False):
         A0 = ctx.gen_unstr(80, 80, 80)
         A = ctx.permute(A0, ctx.bfs_order(A0, rcm=True))
         A0.free()
+    elif asis:  # a mesh numbered at random: no locality at all (the column-slab form, bis_spmv_slab.hip)
+        A = ctx.gen_unstr(80, 80, 80)
     else:
         A = ctx.gen_fem(80, 80, 80)
     N = A.n_rows
@@ -336,8 +339,13 @@ def unstructured_spmv(ctx, launches=20, rcm=False):
     ctx.profile(False)
     n, ms = ctx.profile_read()
     rec = {"workload": ("unstr:80,80,80 RCM-ordered (config 5 as named, the order a mesh is solved in), y = A x" if rcm else
+                        "unstr:80,80,80 as generated (config 5 as named: rows numbered at random, no locality), y = A x" if asis else
                         "fem:80,80,80 (stand-in for Flan_1565), y = A x"), "rows": N, "nnz": A.nnz,
-           "roofline": spmv_roofline(A, ms * 1e-3 / max(n, 1), n, os.path.join(ROOT, "profiles", "spmv_traffic_unstr_rcm.json" if rcm else "spmv_traffic_fem.json"), 80)}
+           "roofline": spmv_roofline(A, ms * 1e-3 / max(n, 1), n, os.path.join(ROOT, "profiles", "spmv_traffic_unstr_rcm.json" if rcm else "spmv_traffic_unstr_asis.json" if asis else "spmv_traffic_fem.json"), 80)}
+    if asis:
+        k, one_ms, slab_ms = A.colslab_info()
+        rec["column_slabs"] = {"slabs": k, "trial_one_pass_ms": one_ms, "trial_slab_passes_ms": slab_ms,
+                               "note": "x (12.3 MB) does not fit an XCD's L2: K passes over column ranges whose x slices do, each continuing the rows' sums (bit-identical y); kept because the build-time trial measured them faster"}
     A.free(); x.free(); y.free()
     return rec
 
@@ -811,6 +819,7 @@ def main():
             out["target_512"] = target_512(ctx)
             out["config5_spmv"] = unstructured_spmv(ctx)
             out["config5_spmv_rcm"] = unstructured_spmv(ctx, rcm=True)
+            out["config5_spmv_asis"] = unstructured_spmv(ctx, asis=True)
     if n1 == 256 and not args.no_sweeps:
         out["sweeps"] = sweep_legs(ctx)
         if not args.no_cpu_baseline:
