@@ -15,6 +15,8 @@ if kind == "unstr_rcm":  # config 5 as a real mesh is multiplied
     A0 = ctx.gen_unstr(n1)
     A = ctx.permute(A0, ctx.bfs_order(A0, rcm=True))
     A0.free()
+elif kind == "unstr_asis":  # config 5 as generated: no locality (column slabs; BIS_SPMV_COLSLAB=0 / 6 pick the one pass / six slabs without a trial)
+    A = ctx.gen_unstr(n1)
 else:
     A = ctx.gen_hpcg(n1) if kind == "hpcg" else ctx.gen_fem(n1) if kind == "fem" else ctx.gen_anderson(n1)
 x, y = ctx.alloc(A.n_rows), ctx.alloc(A.n_rows)
