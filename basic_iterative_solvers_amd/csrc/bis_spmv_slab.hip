@@ -6,7 +6,7 @@
 // A = [A_0 | A_1 | ... | A_{K-1}] whose x slices fit the L2, the K passes  y = A_0 x ; y = y + A_1 x ; ...  gather from the L2
 // (K = 6: 0.53 ms in all).  With the columns of every row ascending, the entries of slab k+1 follow those of slab k in the
 // row, and pass k+1 continues the row's sum where pass k left it: the sum is the reference's left-to-right chain
-// (kernels.hpp:25-39), bit for bit.  Rows that are not ascending refuse the plan.
+// (kernels.hpp:25-39), bit for bit.  A row along which the slab index falls refuses the plan (the order inside a slab is free).
 //
 // Here: the K slab matrices (CRS copies of the column ranges: 12 bytes per non-zero once more) built on the device.
 #include "bis_internal.hpp"
@@ -23,7 +23,7 @@ struct SlabPtrs {
     const int32_t *rp;
 };
 
-// cnt[t * n + r] = entries of row r in slab t; flags[0] |= 1 where a row's columns are not ascending.  A wave per row.
+// cnt[t * n + r] = entries of row r in slab t; flags[0] |= 1 where the slab index falls along a row.  A wave per row.
 __global__ __launch_bounds__(256) void slab_count_kernel(const int32_t *__restrict__ rp, const int32_t *__restrict__ col, int64_t n,
                                                          int width, int K, int32_t *__restrict__ cnt, int *flags) {
     const int lane = threadIdx.x & 63;
@@ -34,15 +34,17 @@ __global__ __launch_bounds__(256) void slab_count_kernel(const int32_t *__restri
     bool unsorted = false;
     for (int64_t base = rp[r]; base < e; base += 64) {
         const bool in = base + lane < e;
-        const int c = in ? col[base + lane] : 0x7fffffff;
-        int before = __shfl_up(c, 1);
+        const int c = in ? col[base + lane] : 0;
+        const int s = in ? min(K - 1, c / width) : 0x7fffffff;
+        // what the passes need is that the SLAB index never falls along the row (ascending columns are the usual reason): the
+        // entries of slab k+1 then follow those of slab k, whatever their order inside a slab
+        int before = __shfl_up(s, 1);
         if (lane == 0) before = prev_last;
-        unsorted |= in && c < before;
+        unsorted |= in && s < before;
         const int left = (int)min((int64_t)64, e - base);
-        prev_last = __shfl(c, left - 1);
-        const int s = in ? min(K - 1, c / width) : -1;
+        prev_last = __shfl(s, left - 1);
         for (int t = 0; t < K; ++t) {
-            const int m = __popcll(__ballot(s == t));
+            const int m = __popcll(__ballot(in && s == t));
             if (lane == t) mine += m;
         }
     }
@@ -116,7 +118,7 @@ bis_status bis_spmv_colslab_build(bis_ctx *ctx, const bis_mat *A, int K, std::ve
     int h = 0;
     BIS_SL_CHECK(hipMemcpyAsync(&h, flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     BIS_SL_CHECK(hipStreamSynchronize(ctx->stream));
-    if (h) return cleanup(BIS_OK); // a row with descending columns: the slabs would reorder its sum
+    if (h) return cleanup(BIS_OK); // a row that returns to an earlier slab: the passes would reorder its sum
     size_t tmp_bytes = 0;
     BIS_SL_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, cnt, rps + 1, (size_t)n, rocprim::plus<int32_t>(), ctx->stream));
     BIS_SL_CHECK(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));

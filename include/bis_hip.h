@@ -192,7 +192,8 @@ BIS_API bis_status bis_mat_retune(bis_ctx *ctx, bis_mat *A);
  * tried, the kernel's time on the first allocation and on the one kept (ms; zeros when the matrix
  * has no such stream or no tuning ran).  For bench / CLI records. */
 BIS_API void bis_mat_win8_tuning(const bis_mat *A, int *trials, double *first_ms, double *kept_ms);
-/* Column slabs (the SpMV's form for a matrix WITHOUT locality: rows ascending, a column stream that does not
+/* Column slabs (the SpMV's form for a matrix WITHOUT locality: rows along which the slab index never falls --
+ * ascending columns, the usual case --, a column stream that does not
  * pack, an x that does not fit an XCD's L2 -- config 5's unstructured input as generated): K CRS copies of
  * column ranges whose x slices fit the L2, multiplied in K passes that continue each row's left-to-right sum
  * (kernels.hpp:25-39: the same sum, bit for bit).  Built at the first SpMV; kept where a trial -- three timed

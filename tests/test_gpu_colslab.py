@@ -104,6 +104,24 @@ def test_colslab_refused_for_rows_that_are_not_ascending(ctx, oracle):
         y = _y(ctx, A, xh, want_form=0, want_k=0)
         yo = oracle.spmv(A, xh)
         assert np.max(np.abs(y - yo)) <= KTOL * np.abs(A.to_scipy()).dot(np.abs(xh)).max()
+        # ... but rows that are only shuffled INSIDE the column ranges of the slabs keep the plan (the slab index never falls)
+        S = scattered(rng, 6000, 20)
+        width = -(-S.n_cols // 4)
+        col = S.col.copy()
+        for r in range(S.n_rows):
+            a, z = S.row_ptr[r], S.row_ptr[r + 1]
+            for t in range(4):
+                idx = a + np.flatnonzero(np.minimum(col[a:z] // width, 3) == t)
+                col[idx] = rng.permutation(col[idx])
+        S2 = CRS(S.n_rows, S.row_ptr, col, S.val, n_cols=S.n_cols)
+        assert (np.diff(col) < 0).sum() > S.n_rows  # (far more descents than row boundaries)
+        xs = rng.uniform(-1, 1, S.n_cols)
+        ctx.set_option("spmv_colslab", 0)
+        y0 = _y(ctx, S2, xs, want_k=0)
+        ctx.set_option("spmv_colslab", 4)
+        y1 = _y(ctx, S2, xs, want_form=7, want_k=4)
+        assert np.array_equal(y0.view(np.uint64), y1.view(np.uint64))
+        assert np.max(np.abs(y1 - oracle.spmv(S2, xs))) <= KTOL * np.abs(S2.to_scipy()).dot(np.abs(xs)).max()
         # ... and duplicates of a column (equal, not descending) are fine
         B = CRS(4, [0, 3, 5, 5, 8], np.array([0, 2, 2, 1, 3, 0, 0, 3], dtype=np.int32), np.arange(1.0, 9.0))
         xb = np.array([1.0, -2.0, 0.5, 4.0])
