@@ -88,6 +88,28 @@ def parse():
     return ap.parse_args()
 
 
+def device_state():
+    """Clocks, package power and temperatures of GPU 0 as rocm-smi reports them right now (called right behind a timed
+    region, never inside one): a record whose kernel ran slower than on another box says whether the device was
+    throttling.  None where rocm-smi is not there or does not answer."""
+    import subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True, timeout=20).stdout
+    except Exception:  # noqa: BLE001
+        return None
+    state = {}
+    for line in txt.splitlines():
+        if ":" not in line or "GPU[" not in line:
+            continue
+        key, _, val = line.split(":", 1)[1].rpartition(":")
+        key, val = key.strip(), val.strip()
+        for tag, name in (("sclk", "sclk"), ("mclk", "mclk"), ("fclk", "fclk"), ("socclk", "socclk"), ("Power", "power_W"),
+                          ("junction", "temp_junction_C"), ("memory", "temp_memory_C"), ("edge", "temp_edge_C")):
+            if tag in key and name not in state:
+                state[name] = val
+    return state or None
+
+
 def host_topology():
     """Sockets / physical cores / logical CPUs of this box and the CPUs this process may run on."""
     topo = {"logical_cpus": os.cpu_count()}
@@ -708,6 +730,7 @@ def main():
     t1 = time.perf_counter()
     ctx.profile(False)
     launches, spmv_ms = ctx.profile_read()
+    state_after_timed = device_state()
     iters, conv, hist = cg.status(hist_cap=args.warmup + args.steps + 1)
     if iters != args.warmup + args.steps:
         raise SystemExit(f"timed region invalid: {iters} iterations executed, "
@@ -746,6 +769,7 @@ def main():
         "cg_frac_of_peak": (12 * nnz + 20 * N + vec_bytes) * its / 1e9 / HBM_PEAK_GBS,
         "residual_r0": r0, "residual_last": float(hist[-1]),
         "roofline": roof,
+        "device_state_after_timed_region": state_after_timed,
     }
     cg.free()
     ctx.set_option("spmv_valdict", -1)
@@ -817,6 +841,7 @@ def main():
         info = ctx.device_info()
         if info["hbm_bytes"] >= 200e9:
             out["target_512"] = target_512(ctx)
+            out["target_512"]["device_state_after_leg"] = device_state()
             out["config5_spmv"] = unstructured_spmv(ctx)
             out["config5_spmv_rcm"] = unstructured_spmv(ctx, rcm=True)
             out["config5_spmv_asis"] = unstructured_spmv(ctx, asis=True)
