@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void symmetry_kernel(const RP *__restrict__ ro
     }
     if (lane == 0) {
         deg[r] = d;
-        if (bad) atomicOr(status, 1);
+        if (bad && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(status, 1);
         if (balance != 0) atomicAdd((unsigned long long *)(status + 6), (unsigned long long)balance);
     }
 }

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void slab_count_kernel(const int32_t *__restri
         }
     }
     if (lane < K) cnt[(size_t)lane * n + r] = mine;
-    if (__ballot(unsorted) && lane == 0) atomicOr(flags, 1);
+    // (one flag for the whole matrix: a matrix whose rows are ALL out of order would queue 1.5 M atomics on it -- 15 ms)
+    if (__ballot(unsorted) && lane == 0 && __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flags, 1);
 }
 
 __global__ __launch_bounds__(256) void slab_fill_kernel(const int32_t *__restrict__ rp, const int32_t *__restrict__ col,
