@@ -53,6 +53,8 @@ struct bis_trsv_plan {
     // few-level orderings whose levels are contiguous row ranges: one row view per level
     std::vector<bis_mat *> level_views;
     std::vector<int64_t> level_row0;
+    int wave_choice = 0;   // level-scheduled kernels: 0 not decided yet, 1 a wave per row, 2 a lane per row (trial at the first sweep, see trsv_solve_impl)
+    float trial_ms[2] = {0.f, 0.f};
 };
 
 void bis_trsv_plan_destroy(bis_trsv_plan *p) {
@@ -688,7 +690,39 @@ bis_status trsv_solve_impl(bis_ctx *ctx, const bis_mat *T, bool backward, double
     // waves: 98 ms per sweep with a wave per row) and the rows still fit two lane batches
     const int64_t avg_width = p->n_levels > 0 ? n / p->n_levels : n;
     const int wave_auto = T->max_row_nnz > 16 || (T->max_row_nnz > 8 && avg_width <= (int64_t)ctx->n_cus * 16);
-    const int wave_mode = bis_opts().trsv_wave >= 0 ? bis_opts().trsv_wave : (wave_auto ? 1 : 0);
+    // Where the rule says "a wave per row" the other kernel is sometimes the faster one (`unstr:80,80,80` as generated, 135 levels of
+    // 11 K rows, 33 entries per row: forward 1.50 ms with a wave per row, 1.21 with a lane per row; backward 1.52 against 3.55), and
+    // nothing known before the sweep tells the cases apart: the first sweep of a large triangle runs both (twice each, the second
+    // run timed; the results are the same bits) and the plan keeps the faster one.  Not inside a device schedule (a stopped
+    // schedule's launches are no-ops), not when x aliases an input (the sweep could not be repeated).
+    if (p->wave_choice == 0 && bis_opts().trsv_wave < 0) {
+        const bool can_try = bis_opts().trsv_trial != 0 && wave_auto && !one_xcd && n >= 200000 && T->max_row_nnz <= 128 &&
+                             x != b && x != D && !ctx->spmv_stop && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_grid <= 0;
+        if (!can_try) {
+            if (ctx->spmv_stop || x == b || x == D) { /* decide at a later sweep */ }
+            else p->wave_choice = wave_auto ? 1 : 2;
+        } else {
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            bool good = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
+            bis_status tst = BIS_OK;
+            for (int v = 1; v <= 2 && good && tst == BIS_OK; ++v) {
+                p->wave_choice = v;
+                for (int rep = 0; rep < 2 && tst == BIS_OK; ++rep) {
+                    if (rep == 1) good = good && hipEventRecord(ev[0], ctx->stream) == hipSuccess;
+                    tst = trsv_solve_impl(ctx, T, backward, x, D, b, kernel);
+                }
+                good = good && hipEventRecord(ev[1], ctx->stream) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess &&
+                       hipEventElapsedTime(&p->trial_ms[v - 1], ev[0], ev[1]) == hipSuccess;
+            }
+            if (ev[0]) hipEventDestroy(ev[0]);
+            if (ev[1]) hipEventDestroy(ev[1]);
+            (void)hipGetLastError();
+            p->wave_choice = (good && tst == BIS_OK && p->trial_ms[1] < 0.9f * p->trial_ms[0]) ? 2 : 1;
+            kernel = p->wave_choice == 1 ? "sptrsv_wave_kernel" : "sptrsv_syncfree_kernel";
+            return tst; // (x holds the solution: the last of the four sweeps)
+        }
+    }
+    const int wave_mode = bis_opts().trsv_wave >= 0 ? bis_opts().trsv_wave : (p->wave_choice ? (p->wave_choice == 1 ? 1 : 0) : (wave_auto ? 1 : 0));
     if (wave_mode && !one_xcd) {
         // a few levels of rows in flight, one row per wave; at most 4 workgroups per CU: every wave of the
         // grid must be resident (static round robin, see the kernel)

@@ -260,3 +260,47 @@ def test_multi_dof_grid_takes_the_chained_sweep_first(ctx, oracle, capfd, monkey
                 assert err.count("tiled sptrsv plan") == 2 and "chained sptrsv plan" not in err, err
         finally:
             ctx.set_option("trsv_tiled", -1)
+
+
+def test_level_sweep_kernel_trial_keeps_the_bits(ctx, oracle):
+    """The level-scheduled sweeps have two kernels (a wave per row, a lane per row); where the rule picks the first, the first
+    sweep of a large triangle times both and the plan keeps the faster one (bis_sptrsv.hip).  Whatever it keeps, x is the
+    same bits as with the trial off and as the oracle's natural-order sweep (kernels.hpp:54-117); a sweep whose x aliases b
+    is not used for the trial."""
+    dA = ctx.gen_unstr(44, 44, 40)  # 232,320 rows as generated: wide levels, no chains
+    n = dA.n_rows
+    rng = np.random.default_rng(9)
+    bh = rng.uniform(-1, 1, n)
+    xs = {}
+    names = {}
+    for trial in (0, -1):
+        ctx.set_option("trsv_trial", trial)
+        try:
+            Ls, Us, D, Dinv = ctx.split_strict(dA)
+            b, x = ctx.upload(bh), ctx.alloc(n)
+            if trial:  # first an aliased sweep: must not decide (and must be right)
+                ctx.copy_vector(x, b)
+                ctx.sptrsv(Ls, x, D, x)
+                xs["aliased"] = x.to_host()
+            for T, solve, d in ((Ls, ctx.sptrsv, "f"), (Us, ctx.bsptrsv, "b")):
+                solve(T, x, D, b)
+                solve(T, x, D, b)
+                xs[(trial, d)] = x.to_host()
+                names[(trial, d)] = T.sweep_kernel(d == "b")
+            if trial == 0:
+                rp, col, val = Ls.download()
+                from oracle.pyoracle import CRS
+                ref = oracle.sptrsv(CRS(n, rp, col, val), D.to_host(), bh, backward=False)
+                assert np.array_equal(ref, xs[(0, "f")])
+            for m in (Ls, Us):
+                m.free()
+            for v in (D, Dinv, b, x):
+                v.free()
+        finally:
+            ctx.set_option("trsv_trial", -1)
+    assert names[(0, "f")] == names[(0, "b")] == "sptrsv_wave_kernel"
+    assert names[(-1, "f")] in ("sptrsv_wave_kernel", "sptrsv_syncfree_kernel") and names[(-1, "b")] in ("sptrsv_wave_kernel", "sptrsv_syncfree_kernel")
+    for d in ("f", "b"):
+        assert np.array_equal(xs[(0, d)].view(np.uint64), xs[(-1, d)].view(np.uint64))
+    assert np.array_equal(xs["aliased"].view(np.uint64), xs[(0, "f")].view(np.uint64))
+    dA.free()
