@@ -696,9 +696,9 @@ bis_status trsv_solve_impl(bis_ctx *ctx, const bis_mat *T, bool backward, double
     // run timed; the results are the same bits) and the plan keeps the faster one.  Not inside a device schedule (a stopped
     // schedule's launches are no-ops), not when x aliases an input (the sweep could not be repeated).
     if (p->wave_choice == 0 && bis_opts().trsv_wave < 0) {
-        // (wide levels only: on narrow ones a lane per row is hopeless -- `unstr:80,80,80` RCM-ordered, 215 rows per level: 105 ms
+        // (levels of 1024 rows or more only: on narrow ones a lane per row is hopeless -- `unstr:80,80,80` RCM-ordered, 215 rows per level: 105 ms
         // against 13 with a wave per row -- and the trial itself would cost more than it can win)
-        const bool can_try = bis_opts().trsv_trial != 0 && wave_auto && !one_xcd && n >= 200000 && T->max_row_nnz <= 128 && avg_width >= 2048 &&
+        const bool can_try = bis_opts().trsv_trial != 0 && wave_auto && !one_xcd && n >= 200000 && T->max_row_nnz <= 128 && avg_width >= 1024 &&
                              x != b && x != D && !ctx->spmv_stop && bis_opts().trsv_inject_loss <= 0 && bis_opts().trsv_grid <= 0;
         if (!can_try) {
             if (ctx->spmv_stop || x == b || x == D) { /* decide at a later sweep */ }
