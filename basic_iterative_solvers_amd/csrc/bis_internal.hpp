@@ -71,6 +71,7 @@ struct bis_options {
     int ilu0_persistent = -1; // 0: a launch per level (default: one persistent launch, a flag per finished row)
     int trsv_host_analysis = -1; // 1: level analysis on the host (default: on the device)
     int trsv_wave = -1;    // 1: one wave per row in the sync-free sweeps (default for rows > 16)
+    int trsv_wave_wgs = -1; // wave-per-row level sweep: workgroups per CU (default 4; up to the 8 the runtime reports resident)
     int trsv_trial = -1;   // 0: the level-scheduled sweeps never time their two kernels against each other (default: the first sweep of a large triangle does)
     int trsv_batch = -1;   // dependencies polled per round trip (4, 8, 16; -1: by row length)
     int trsv_by_pos = -1;  // 1 (default): sentinel scratch in level order; 0: in row order

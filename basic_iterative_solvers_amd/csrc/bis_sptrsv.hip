@@ -739,15 +739,19 @@ bis_status trsv_solve_impl(bis_ctx *ctx, const bis_mat *T, bool backward, double
             int nb = 0;
             hipError_t oe = T->rp64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sptrsv_wave_kernel<int64_t>, kTrsvT, 0)
                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sptrsv_wave_kernel<int32_t>, kTrsvT, 0);
-            res = (oe == hipSuccess && nb > 0) ? std::min(nb, kWaveBlocksPerCU) : 1;
+            res = (oe == hipSuccess && nb > 0) ? std::min(nb, 8) : 1; // (what the runtime reports: 8 at 30 VGPRs; the launch bound guarantees 4)
             (void)hipGetLastError();
         }
+        // workgroups per CU: 4 on narrow levels (more idle pollers slow the hand-offs), 6 on levels of >= 1024 rows, where the rows in
+        // flight are what counts (`unstr:80,80,80` as generated, 11 K rows per level: 2.51 / 1.49 / 1.27 / 1.38 ms at 2 / 4 / 6 / 8);
+        // option trsv_wave_wgs: up to what the runtime reports resident
+        const int per_cu = std::min(res, bis_opts().trsv_wave_wgs > 0 ? bis_opts().trsv_wave_wgs : (avg_width >= 1024 ? 6 : kWaveBlocksPerCU));
         int64_t wg = (4 * p->max_level_width + 3) / 4 + 1;
         if (bis_opts().trsv_grid > 0) wg = bis_opts().trsv_grid;
         // option "device_share" = k: k processes run sweeps on this device at the same time (ranks of a test or a rehearsal
         // sharing one GPU), each keeps to 1/k of the residency so that all their grids fit together
         const int share = std::max(1, bis_opts().device_share);
-        wg = std::max<int64_t>(1, std::min<int64_t>(wg, std::min<int64_t>((n + 3) / 4, std::max<int64_t>(1, (int64_t)ctx->n_cus * res / share))));
+        wg = std::max<int64_t>(1, std::min<int64_t>(wg, std::min<int64_t>((n + 3) / 4, std::max<int64_t>(1, (int64_t)ctx->n_cus * per_cu / share))));
         if (T->rp64)
             hipLaunchKernelGGL(sptrsv_wave_kernel<int64_t>, dim3((unsigned)wg), dim3(kTrsvT), 0, ctx->stream,
                                (const int64_t *)T->row_ptr, dep, T->val, p->perm, n, D, b, x,

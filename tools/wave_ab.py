@@ -13,7 +13,7 @@ N = A.n_rows
 Ls, Us, D, Dinv = ctx.split_strict(A)
 b = ctx.upload(np.random.default_rng(21).uniform(-1, 1, N))
 ref = None
-for name, opts in (("default", {}), ("lane per row (trsv_wave 0)", {"trsv_wave": 0}), ("wave, batch 16", {"trsv_batch": 16}), ("wave, batch 4", {"trsv_batch": 4}),
+for name, opts in (("default", {}), ("wave per row, 8 workgroups per CU", {"trsv_wave": 1, "trsv_wave_wgs": 8}), ("wave per row, 6 per CU", {"trsv_wave": 1, "trsv_wave_wgs": 6}), ("wave per row, 4 per CU", {"trsv_wave": 1}), ("wave per row, 2 per CU", {"trsv_wave": 1, "trsv_wave_wgs": 2}), ("lane per row (trsv_wave 0)", {"trsv_wave": 0}), ("wave, batch 16", {"trsv_batch": 16}), ("wave, batch 4", {"trsv_batch": 4}),
                    ("scratch in row order (trsv_by_pos 0)", {"trsv_by_pos": 0}), ("a launch per level (trsv_grid 0?)", {"trsv_one_xcd": 2})):
     for k, v in opts.items():
         ctx.set_option(k, v)

@@ -15,7 +15,7 @@ N = A.n_rows
 b = ctx.upload(np.random.default_rng(21).uniform(-1, 1, N))
 ref = None
 for name, opts in (("default (chained)", {}), ("level-scheduled, wave per row", {"trsv_chain": 0, "trsv_wave": 1}),
-                   ("level-scheduled, lane per row", {"trsv_chain": 0, "trsv_wave": 0}), ("level-scheduled, trial", {"trsv_chain": 0})):
+                   ("level-scheduled, wave per row, 6 per CU", {"trsv_chain": 0, "trsv_wave": 1, "trsv_wave_wgs": 6}), ("level-scheduled, wave per row, 2 per CU", {"trsv_chain": 0, "trsv_wave": 1, "trsv_wave_wgs": 2}), ("level-scheduled, wave per row, 1 per CU", {"trsv_chain": 0, "trsv_wave": 1, "trsv_wave_wgs": 1}), ("level-scheduled, trial", {"trsv_chain": 0})):
     for k, v in opts.items():
         ctx.set_option(k, v)
     L2, U2, D2, Di2 = ctx.split_strict(A)
