@@ -270,7 +270,7 @@ bis_status bis_fault_check(bis_ctx *ctx) {
 // ---- options: ONE table drives the environment, bis_set_option and bis_options_describe ---------------------------
 // X(name): settable through bis_set_option("name", v) AND, at first use, the environment variable BIS_<NAME>;
 // Y(name): bis_set_option only (per-call tuning knobs and test hooks: nothing a stray environment should reach).
-#define BIS_OPTIONS_ENV(X) X(spmv_variant) X(spmv_window) X(spmv_chunk) X(spmv_chunk_fused) X(spmv_xcd_remap) X(trsv_grid) X(trsv_wave_wgs) X(trsv_trial) X(trsv_one_xcd) X(trsv_host_analysis) X(ilu0_wave) X(spmv_packed) X(spmv_packed32) X(spmv_valdict) X(spmv_sellwin) X(device_share) X(spmv_sellwin_rows) X(spmv_sellwin_joint) X(spmv_sellwin_pairs) X(spmv_sellwin_masks) X(spmv_colslab) X(spmv_win8) X(spmv_win8_rows) X(spmv_win8_depth) X(spmv_win8_tune) X(grid_autodetect) X(tune_placement) X(cg_graph) X(force_rp64) X(trsv_tiled) X(trsv_chain) X(trsv_tile_rows) X(trsv_tile_wgs) X(trsv_tile_edge) X(trsv_tile_backoff)
+#define BIS_OPTIONS_ENV(X) X(spmv_variant) X(spmv_window) X(spmv_chunk) X(spmv_chunk_fused) X(spmv_xcd_remap) X(trsv_grid) X(ilu0_wgs) X(trsv_wave_wgs) X(trsv_trial) X(trsv_one_xcd) X(trsv_host_analysis) X(ilu0_wave) X(spmv_packed) X(spmv_packed32) X(spmv_valdict) X(spmv_sellwin) X(device_share) X(spmv_sellwin_rows) X(spmv_sellwin_joint) X(spmv_sellwin_pairs) X(spmv_sellwin_masks) X(spmv_colslab) X(spmv_win8) X(spmv_win8_rows) X(spmv_win8_depth) X(spmv_win8_tune) X(grid_autodetect) X(tune_placement) X(cg_graph) X(force_rp64) X(trsv_tiled) X(trsv_chain) X(trsv_tile_rows) X(trsv_tile_wgs) X(trsv_tile_edge) X(trsv_tile_backoff)
 #define BIS_OPTIONS_API(Y) Y(trsv_batch) Y(trsv_wave) Y(ilu0_persistent) Y(trsv_by_pos) Y(spmv_lds_pad) Y(trsv_chain_idle) Y(trsv_chain_pause) Y(trsv_chain_pairs) Y(trsv_chain_prefix) Y(trsv_tile_exp) Y(cg_nt_x) Y(spmv_sellwin_nt) Y(dist_host_plan) Y(trsv_inject_loss) Y(trsv_inject_oom)
 
 namespace {

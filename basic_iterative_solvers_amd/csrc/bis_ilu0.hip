@@ -391,7 +391,12 @@ bis_status ilu0_t(bis_ctx *ctx, const bis_mat *A, double pivot_tol, double pivot
         int *flag = nullptr;
         if (oe == hipSuccess && nb > 0 && hipMalloc(&flag, sizeof(int) * (size_t)n) == hipSuccess) {
             const int share = std::max(1, bis_opts().device_share);
-            const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->n_cus * std::min(nb, 4) / share));
+            // workgroups per CU: 6 of the 8 the runtime reports resident (round 5; whole call at 2 / 4 / 6 / 7 per CU: `unstr:80,80,80` as
+            // generated 72 / 50 / 42 / 40 ms, RCM-ordered 92 / 78 / 74 / 74, fem:80,80,81 79 / 63 / 57 / 56 -- `tools/ilu_ab.py`).  NOT all 8: the
+            // rows are dealt statically, every workgroup must be resident, and a grid that needs every slot of every CU does not always
+            // get them (8 per CU: the run ended with BIS_ERR_SYNC -- loudly, as designed -- on the first try); option ilu0_wgs
+            const int per_cu = std::min(nb, bis_opts().ilu0_wgs > 0 ? bis_opts().ilu0_wgs : 6);
+            const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->n_cus * per_cu / share));
             hipMemsetAsync(flag, 0, sizeof(int) * (size_t)n, ctx->stream);
             hipLaunchKernelGGL(ilu0_persistent_kernel<RP>, dim3((unsigned)grid), dim3(256), smem, ctx->stream, rp, W->col, W->val, dpos, ustart,
                                perm, n, pivot_tol, pivot_repl, U_D, L_D, mr, flag, ctx->fault_dev);

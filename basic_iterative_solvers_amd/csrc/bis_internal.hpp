@@ -68,6 +68,7 @@ struct bis_options {
     int spmv_xcd_remap = -1; // 1: each XCD sweeps its own slab of row blocks (default: blockIdx order)
     int trsv_grid = -1;    // -1: automatic
     int ilu0_wave = -1;    // 0: lane-per-row ILU(0) level kernel (default: wave per row)
+    int ilu0_wgs = -1;     // persistent ILU(0): workgroups per CU (default 6; never all 8 the runtime reports: the grid must be resident as a whole)
     int ilu0_persistent = -1; // 0: a launch per level (default: one persistent launch, a flag per finished row)
     int trsv_host_analysis = -1; // 1: level analysis on the host (default: on the device)
     int trsv_wave = -1;    // 1: one wave per row in the sync-free sweeps (default for rows > 16)

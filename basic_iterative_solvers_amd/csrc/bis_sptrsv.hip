@@ -744,7 +744,8 @@ bis_status trsv_solve_impl(bis_ctx *ctx, const bis_mat *T, bool backward, double
         }
         // workgroups per CU: 4 on narrow levels (more idle pollers slow the hand-offs), 6 on levels of >= 1024 rows, where the rows in
         // flight are what counts (`unstr:80,80,80` as generated, 11 K rows per level: 2.51 / 1.49 / 1.27 / 1.38 ms at 2 / 4 / 6 / 8);
-        // option trsv_wave_wgs: up to what the runtime reports resident
+        // option trsv_wave_wgs: up to what the runtime reports resident (a grid that needs all 8 slots of every CU does not always get
+        // them -- see bis_ilu0.hip --: 6 leaves a quarter of the slots spare)
         const int per_cu = std::min(res, bis_opts().trsv_wave_wgs > 0 ? bis_opts().trsv_wave_wgs : (avg_width >= 1024 ? 6 : kWaveBlocksPerCU));
         int64_t wg = (4 * p->max_level_width + 3) / 4 + 1;
         if (bis_opts().trsv_grid > 0) wg = bis_opts().trsv_grid;
