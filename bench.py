@@ -443,7 +443,7 @@ def load_sweep_traffic(key, direction, algorithmic):
         t = tj["sweeps"][key][direction]["hbm_bytes_per_sweep"]
     except Exception:
         return None
-    return t if t and 0.9 * algorithmic <= t <= 3.0 * algorithmic else None
+    return t if t and 0.9 * algorithmic <= t <= 12.0 * algorithmic else None
 
 
 def sweep_legs(ctx, sweeps=10, warm=3, only=None):

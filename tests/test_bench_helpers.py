@@ -79,6 +79,8 @@ def test_sweep_traffic_guard(tmp_path, monkeypatch):
     (d / "trsv_traffic.json").write_text(json.dumps({"sweeps": {"k": {"forward": {"hbm_bytes_per_sweep": 2.0e9}, "backward": {"hbm_bytes_per_sweep": 5.0e10}}}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.load_sweep_traffic("k", "forward", 1.0e9) == 2.0e9
+    assert bench.load_sweep_traffic("k", "forward", 0.25e9) == 2.0e9     # 8x: an ordering without locality (a line per 8-byte operand)
+    assert bench.load_sweep_traffic("k", "forward", 0.15e9) is None      # 13x
     assert bench.load_sweep_traffic("k", "backward", 1.0e9) is None     # 50x: not this workload's sweep
     assert bench.load_sweep_traffic("k", "forward", 4.0e9) is None      # fewer bytes than the algorithm needs
     assert bench.load_sweep_traffic("other", "forward", 1.0e9) is None
